@@ -1,0 +1,113 @@
+/* yolop.h - C-ABI of libyolop.so: the MI355X-native YOLOv10 predict hot path.
+ *
+ * The reference (daisy9542/yolo-puncture) has NO native/FFI layer for this path: its boundary is the Python call
+ * `ultralytics.YOLO(path).predict(source, conf=, retina_masks=, device=)` (yolo_seg/app.py:45,49,91;
+ * yolo_seg/yolo_with_deva.py:51,226; dev_tools/auto_speed_calc.py:40,62;
+ * dev_tools/classify/cls_bbox_dataset_generate.py:48,66). Each entry point below names the part of that call
+ * it replaces. The Python facade in yolo-puncture_amd/predictor.py binds these with ctypes.
+ *
+ * Conventions: every function returns 0 on success, <0 on error; yp_last_error() returns a thread-local
+ * message. All device pointers are raw HIP device addresses owned by the CALLER (PyTorch tensors'
+ * data_ptr()); the engine owns packed weights + its activation workspace. Work is enqueued on the stream
+ * passed in (a hipStream_t cast to void*; NULL = default stream) with no hidden synchronisation.
+ * An engine is bound to one device and is not re-entrant: one engine per GPU, one caller thread at a time.
+ */
+#ifndef YOLOP_H
+#define YOLOP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YP_OK 0
+#define YP_ERR_ARG -1      /* bad argument / shape                */
+#define YP_ERR_STATE -2    /* call order (e.g. forward before finalize) */
+#define YP_ERR_HIP -3      /* a HIP runtime call failed           */
+#define YP_ERR_WEIGHT -4   /* unknown / missing / mis-shaped weight */
+
+#define YP_BF16 0          /* activations+weights bf16 in HBM, fp32 accumulate (MFMA 16x16x32 bf16) */
+#define YP_F32 1           /* everything fp32 (MFMA 16x16x4 f32): strict-parity mode               */
+
+#define YP_TASK_DETECT 0
+#define YP_TASK_SEGMENT 1
+
+#define YP_NM 32           /* mask coefficients per detection */
+
+typedef struct yp_engine yp_engine;
+
+/* What `YOLO(path)` learns from the checkpoint's yaml: which graph to build. */
+typedef struct yp_model_desc {
+    int variant; /* ASCII 'n','s','m','b','l','x'                                */
+    int nc;      /* number of classes                                             */
+    int task;    /* YP_TASK_DETECT | YP_TASK_SEGMENT (v10 trunk + Proto/cv4 head) */
+    int dtype;   /* YP_BF16 | YP_F32                                              */
+    int max_det; /* 300 (ultralytics default); top-k size of the one-to-one head  */
+} yp_model_desc;
+
+const char* yp_last_error(void);
+
+/* -- construction: replaces `YOLO(path)` (yolo_seg/app.py:45). Builds the op graph on the host; touches no GPU
+ *    state, so it also works (for inspection) on a box without a GPU. device = HIP ordinal used later. */
+int yp_create(const yp_model_desc* desc, int device, yp_engine** out);
+int yp_destroy(yp_engine* e);
+
+/* The folded (Conv+BN merged) parameters the graph expects, e.g. "model.0.weight" [32,3,3,3], "model.0.bias" [32]. */
+int yp_weight_count(const yp_engine* e);
+int yp_weight_info(const yp_engine* e, int i, char* name, int name_cap, int64_t shape[4], int* ndim);
+
+/* Hand one folded fp32 parameter (HOST pointer) to the engine; it is repacked to the kernel layout
+ * ([Cout][ky][kx][Cin], K padded) in the engine dtype. Replaces the state-dict load inside YOLO(path). */
+int yp_set_weight(yp_engine* e, const char* name, const float* host, const int64_t* shape, int ndim);
+
+/* Verify every parameter was set, upload packed weights to the device. After this the engine can run. */
+int yp_finalize(yp_engine* e);
+
+/* -- the forward + NMS-free post-process: replaces predictor inference + `v10postprocess` inside
+ *    `.predict(...)` (yolo_seg/app.py:91). in_dev: uint8 NHWC **BGR**, already letterboxed, [B,H,W,3], H and W
+ *    multiples of 32. Outputs (device, caller-owned):
+ *      det_out   float [B,max_det,6] = x1,y1,x2,y2 (letterboxed-input pixels), score, class; rows sorted by
+ *                score descending, ties by (stage-1 rank, class) ascending
+ *      idx_out   int32 [B,max_det] anchor index of each row (may be NULL)
+ *      coeff_out float [B,max_det,32] mask coefficients of each row (segment task; may be NULL)
+ *    If the image has fewer than max_det anchors, k = #anchors rows are valid and the rest are zero. */
+int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
+               float* coeff_out, void* stream);
+
+/* Engine-owned prototype tensor of the last forward (segment task): NHWC [B,Hp,Wp,32] in the engine dtype. */
+int yp_proto(const yp_engine* e, const void** proto_dev, int* Hp, int* Wp);
+
+/* -- segmentation tail: replaces ops.process_mask_native / process_mask + the id painting loop of
+ *    `auto_segment` (yolo_seg/yolo_with_deva.py:54-86).
+ *    image b of the last forward; n rows of coeff [n,32] (device float) and boxes [n,4] (device float):
+ *    retina != 0: boxes in ORIGINAL-image pixels, masks at (oh,ow)      (process_mask_native)
+ *    retina == 0: boxes in letterboxed-input pixels, masks at (oh,ow)=(H,W) of the forward (process_mask)
+ *    masks_out: uint8 [n,oh,ow] in {0,1} (may be NULL)
+ *    id_out:    int64 [oh,ow] painted ids (may be NULL): rows in order, later overwrite earlier, rows whose
+ *               area < min_area are skipped when suppress_small != 0, ids consecutive over kept rows
+ *    kept_out:  int32 [n] id assigned to each row (0 = suppressed) (may be NULL; needs id_out)          */
+int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev, int n, int oh, int ow,
+             int retina, uint8_t* masks_out, int64_t* id_out, int32_t* kept_out, int suppress_small,
+             int min_area, void* stream);
+
+/* -- introspection (tests, bench): the planned op list for an input shape; host only. */
+int yp_plan(yp_engine* e, int B, int H, int W);            /* (re)build the plan; returns #ops or <0 */
+int yp_op_info(const yp_engine* e, int i, char* name, int name_cap, int* kind, double* flops,
+               double* bytes);                                 /* algorithmic FLOPs / HBM bytes of op i */
+int yp_op_output(const yp_engine* e, int i, int* tensor, int* coff, int* C); /* output channel slice of op i (tensor<0: user buffers) */
+int yp_tensor_count(const yp_engine* e);
+int yp_tensor_info(const yp_engine* e, int i, char* name, int name_cap, int dims[4] /*B,H,W,C*/, int* is_f32);
+int yp_tensor_read(yp_engine* e, int i, float* host_out);  /* sync copy NHWC -> fp32 host (debug taps) */
+
+/* Run the plan op by op with a HIP event pair around every launch on `stream`; ms_out[#ops]. */
+int yp_profile(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
+               float* coeff_out, float* ms_out, int iters, void* stream);
+
+/* Enable/disable hipGraph capture+replay of the forward (default on after the first eager run). */
+int yp_set_graph(yp_engine* e, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLOP_H */

@@ -1,0 +1,164 @@
+// Internal types shared by the graph builder, the executor and the HIP kernels (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+namespace yp {
+
+enum DType { DT_BF16 = 0, DT_F32 = 1 };
+enum Act { ACT_NONE = 0, ACT_SILU = 1 };
+
+enum OpKind {
+    OP_STEM = 0,      // u8 BGR NHWC -> first 3x3 s2 conv (+/255, BGR->RGB fused)
+    OP_CONV = 1,      // dense conv k in {1,3}, s in {1,2}: implicit GEMM on MFMA, fused bias/SiLU/residual
+    OP_DWCONV = 2,    // depthwise k in {3,7}
+    OP_POOL5 = 3,     // max-pool 5x5 s1 p2 (SPPF)
+    OP_UPSAMPLE = 4,  // nearest x2
+    OP_ATTN = 5,      // PSA attention core: softmax(q^T k * scale) applied to v
+    OP_HEAD = 6,      // DFL decode + sigmoid + two-stage top-k
+    OP_CONVT = 7,     // ConvTranspose2d k2 s2 (Proto) = 4 strided 1x1 GEMMs
+};
+
+// Channel slice of an NHWC tensor: element (b,y,x,c) at ((b*H+y)*W+x)*pix_stride + coff + c
+struct View {
+    int t = -1;    // tensor id
+    int coff = 0;  // first channel
+    int C = 0;     // channels in the slice
+};
+
+struct TensorDesc {
+    std::string name;
+    int C = 0;
+    int sdiv = 1;        // spatial size = input size / sdiv
+    bool f32 = false;    // fp32 regardless of engine dtype (head logits)
+    // resolved by the plan:
+    int H = 0, W = 0;
+    size_t bytes = 0;
+    void* ptr = nullptr;
+};
+
+struct WeightDesc {
+    std::string name;    // folded name, e.g. "model.2.cv1" ; parameters "<name>.weight" / "<name>.bias"
+    int cout = 0, cin_g = 0, k = 1, groups = 1;
+    bool transposed = false;   // ConvTranspose2d layout [Cin][Cout][k][k]
+    bool is_stem = false;
+    bool have_w = false, have_b = false;
+    std::vector<float> w, b;   // host fp32 copies until finalize
+    // device, packed
+    void* d_w = nullptr;       // layout depends on the consumer kernel
+    float* d_b = nullptr;
+    int Kpad = 0;
+};
+
+struct Op {
+    int kind = OP_CONV;
+    std::string name;
+    View in, out, res;
+    int widx = -1;
+    int k = 1, s = 1, act = ACT_NONE;
+    int gs = 0, gstride = 0;      // depthwise input channel gather: in_ch = coff + (c/gs)*gstride + c%gs (gs=0: identity)
+    int nh = 0, kd = 0, hd = 0;   // attention
+    View box[3], cls[3], cf[3];   // head inputs per level
+    int nlev = 0;
+    double flops = 0, bytes = 0;  // algorithmic (filled by the plan)
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Kernel parameter blocks (passed by value)
+// ---------------------------------------------------------------------------------------------------------
+struct ConvParams {
+    const void* x; int x_stride, x_coff;        // input view (elements)
+    int H, W, Cin;
+    const void* w; int Kpad;                    // packed [CoutPad][Kpad], k order (ky,kx,ci)
+    const float* bias;
+    void* y; int y_stride, y_coff; int Ho, Wo, Cout;
+    const void* res; int res_stride, res_coff;  // nullable; added after the activation
+    int M;                                      // B*Ho*Wo
+    int ks, stride, pad;
+    int act, out_f32;
+    int up, oy, ox;                             // output pixel (ho,wo) -> (ho*up+oy, wo*up+ox) in an (Ho*up,Wo*up) image
+};
+
+struct DwParams {
+    const void* x; int x_stride, x_coff; int H, W, C;
+    const void* w;             // packed [k*k][C]
+    const float* bias;
+    void* y; int y_stride, y_coff; int Ho, Wo;
+    const void* res; int res_stride, res_coff;
+    int B, ks, stride, pad, act;
+    int gs, gstride;
+};
+
+struct StemParams {
+    const uint8_t* x; int H, W;       // [B,H,W,3] BGR
+    const float* w;                   // [3][3][3(bgr)][C0]
+    const float* bias;
+    void* y; int y_stride, y_coff; int Ho, Wo, C0; int B;
+    int act;
+};
+
+struct PoolParams {
+    const void* x; int x_stride, x_coff;
+    void* y; int y_stride, y_coff;
+    int B, H, W, C;
+};
+
+struct UpParams {
+    const void* x; int x_stride, x_coff;
+    void* y; int y_stride, y_coff;
+    int B, H, W, C;   // input dims; output 2H x 2W
+};
+
+struct AttnParams {
+    const void* qkv; int q_stride, q_coff;   // [B,N,nh*(2kd+hd)]
+    void* o; int o_stride, o_coff;           // [B,N,nh*hd]
+    int B, N, nh, kd, hd;
+    float scale;
+};
+
+struct HeadParams {
+    const float* box[3]; const float* cls[3]; const float* cf[3];   // fp32 NHWC logits per level
+    int hw[3][2]; int nlev;
+    int B, nc, max_det, A;
+    float* det; int32_t* idx; float* coeff;   // user outputs
+};
+
+// launches (implemented in the .hip files); dtype selects the template instance
+hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st);
+hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st);
+hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st);
+hipError_t launch_pool5(const PoolParams& p, int dtype, hipStream_t st);
+hipError_t launch_upsample(const UpParams& p, int dtype, hipStream_t st);
+hipError_t launch_attention(const AttnParams& p, int dtype, hipStream_t st);
+hipError_t launch_head(const HeadParams& p, hipStream_t st);
+
+struct MaskParams {
+    const void* proto; int Hp, Wp;        // [Hp,Wp,32] engine dtype (one image)
+    const float* coeff; const float* boxes; int n;
+    int oh, ow;                           // output size
+    int t, l, ch, cw;                     // crop rectangle of the proto image that maps onto (oh,ow) (retina) or full
+    float bsx, bsy;                       // box scale applied before cropping (process_mask: mw/iw, mh/ih ; retina: 1)
+    int crop_before;                      // 1: process_mask (crop at proto res then upsample), 0: native (upsample then crop)
+    uint8_t* masks; int64_t* ids; int32_t* kept; int32_t* area;
+    int suppress_small, min_area;
+};
+hipError_t launch_masks(const MaskParams& p, int dtype, hipStream_t st);
+
+// host-side float -> bf16 (round to nearest even), as the device's v_cvt_pk_bf16_f32
+static inline uint16_t f2bf(float f) {
+    uint32_t u;
+    __builtin_memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf2f(uint16_t h) {
+    uint32_t u = ((uint32_t)h) << 16;
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+}
+
+}  // namespace yp

@@ -1,0 +1,832 @@
+// libyolop.so: native graph builder + executor behind the C-ABI of include/yolop.h.
+//
+// yp_create builds the YOLOv10 op graph (SURVEY.md Appendix A.3/A.4 [U]) for a variant from its scale
+// triple - the job ultralytics' parse_model does inside `YOLO(path)` (reference yolo_seg/app.py:45) - with
+// every `Concat`/`chunk` resolved at build time into channel-slice views of shared NHWC buffers, so no copy
+// kernel exists for them. yp_forward replays the op list on a HIP stream (optionally as one hipGraph).
+#include "../../include/yolop.h"
+#include "common.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+
+using namespace yp;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t _e = (x);                                                                        \
+        if (_e != hipSuccess) return fail(YP_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+struct yp_engine {
+    yp_model_desc desc{};
+    int device = 0;
+    int dtype = DT_BF16;
+    std::vector<TensorDesc> tensors;
+    std::vector<WeightDesc> weights;
+    std::vector<Op> ops;
+    std::map<std::string, int> wmap;
+    bool finalized = false;
+    // plan
+    int pB = 0, pH = 0, pW = 0;
+    bool planned = false, allocated = false;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    int proto_t = -1;
+    void* mask_ws = nullptr;
+    size_t mask_ws_bytes = 0;
+    // hipGraph replay
+    bool use_graph = false;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    struct Key { int B, H, W; const void* in; void* det; void* idx; void* coeff; } gkey{};
+    int es() const { return dtype == DT_BF16 ? 2 : 4; }
+};
+
+// =========================================================================================================
+// graph builder
+// =========================================================================================================
+namespace {
+
+struct Scale { double depth, width; int maxc; };
+static bool variant_scale(int v, Scale& s) {
+    switch (v) {
+        case 'n': s = {0.33, 0.25, 1024}; return true;
+        case 's': s = {0.33, 0.50, 1024}; return true;
+        case 'm': s = {0.67, 0.75, 768}; return true;
+        case 'b': s = {0.67, 1.00, 512}; return true;
+        case 'l': s = {1.00, 1.00, 512}; return true;
+        case 'x': s = {1.00, 1.25, 512}; return true;
+    }
+    return false;
+}
+static int make_div8(double x) { return (int)std::ceil(x / 8.0) * 8; }
+static int py_round(double x) {   // Python round(): half to even
+    double r = std::nearbyint(x);
+    return (int)r;
+}
+
+struct Builder {
+    yp_engine& e;
+    explicit Builder(yp_engine& en) : e(en) {}
+
+    int tensor(const std::string& name, int C, int sdiv, bool f32 = false) {
+        TensorDesc t;
+        t.name = name; t.C = C; t.sdiv = sdiv; t.f32 = f32;
+        e.tensors.push_back(t);
+        return (int)e.tensors.size() - 1;
+    }
+    View full(int t) const { return View{t, 0, e.tensors[t].C}; }
+    static View slice(View v, int off, int C) { return View{v.t, v.coff + off, C}; }
+
+    int weight(const std::string& name, int cout, int cin_g, int k, int groups, bool transposed = false, bool stem = false) {
+        WeightDesc w;
+        w.name = name; w.cout = cout; w.cin_g = cin_g; w.k = k; w.groups = groups; w.transposed = transposed; w.is_stem = stem;
+        e.weights.push_back(w);
+        e.wmap[name] = (int)e.weights.size() - 1;
+        return (int)e.weights.size() - 1;
+    }
+    // dense conv (+folded BN) (+SiLU) (+residual)
+    void conv(const std::string& name, View in, View out, int k, int s, int act, View res = View{}) {
+        Op o;
+        o.kind = OP_CONV; o.name = name; o.in = in; o.out = out; o.res = res; o.k = k; o.s = s; o.act = act;
+        o.widx = weight(name, out.C, in.C, k, 1);
+        e.ops.push_back(o);
+    }
+    void dwconv(const std::string& name, View in, View out, int k, int s, int act, View res = View{}, int gs = 0, int gstride = 0) {
+        Op o;
+        o.kind = OP_DWCONV; o.name = name; o.in = in; o.out = out; o.res = res; o.k = k; o.s = s; o.act = act;
+        o.gs = gs; o.gstride = gstride;
+        o.widx = weight(name, out.C, 1, k, out.C);
+        e.ops.push_back(o);
+    }
+    int sdiv_of(View v) const { return e.tensors[v.t].sdiv; }
+
+    // C2f / C2fCIB (A.2): cv1 -> chunk(2) -> n x (Bottleneck | CIB) -> cat -> cv2, all inside one concat buffer
+    void c2f(const std::string& p, View in, View out, int c2, int n, bool shortcut, bool cib, bool lk) {
+        const int c = c2 / 2, sd = sdiv_of(in);
+        const int Y = tensor(p + ".cat", (2 + n) * c, sd);
+        conv(p + ".cv1", in, View{Y, 0, 2 * c}, 1, 1, ACT_SILU);
+        for (int j = 0; j < n; ++j) {
+            const View x{Y, (1 + j) * c, c}, y{Y, (2 + j) * c, c};
+            const std::string q = p + ".m." + std::to_string(j);
+            const View res = shortcut ? x : View{};
+            if (!cib) {
+                const int t = tensor(q + ".cv1", c, sd);
+                conv(q + ".cv1", x, full(t), 3, 1, ACT_SILU);
+                conv(q + ".cv2", full(t), y, 3, 1, ACT_SILU, res);
+            } else {
+                const int t0 = tensor(q + ".cv1.0", c, sd), t1 = tensor(q + ".cv1.1", 2 * c, sd);
+                const int t2 = tensor(q + ".cv1.2", 2 * c, sd), t3 = tensor(q + ".cv1.3", c, sd);
+                dwconv(q + ".cv1.0", x, full(t0), 3, 1, ACT_SILU);
+                conv(q + ".cv1.1", full(t0), full(t1), 1, 1, ACT_SILU);
+                dwconv(q + ".cv1.2", full(t1), full(t2), lk ? 7 : 3, 1, ACT_SILU);   // RepVGGDW pre-merged to one 7x7
+                conv(q + ".cv1.3", full(t2), full(t3), 1, 1, ACT_SILU);
+                dwconv(q + ".cv1.4", full(t3), y, 3, 1, ACT_SILU, res);
+            }
+        }
+        conv(p + ".cv2", full(Y), out, 1, 1, ACT_SILU);
+    }
+    void scdown(const std::string& p, View in, View out) {
+        const int t = tensor(p + ".cv1", out.C, sdiv_of(in));
+        conv(p + ".cv1", in, full(t), 1, 1, ACT_SILU);
+        dwconv(p + ".cv2", full(t), out, 3, 2, ACT_NONE);
+    }
+    void sppf(const std::string& p, View in, View out) {
+        const int c_ = in.C / 2, sd = sdiv_of(in);
+        const int S = tensor(p + ".cat", 4 * c_, sd);
+        conv(p + ".cv1", in, View{S, 0, c_}, 1, 1, ACT_SILU);
+        for (int i = 0; i < 3; ++i) {
+            Op o;
+            o.kind = OP_POOL5; o.name = p + ".m" + std::to_string(i);
+            o.in = View{S, i * c_, c_}; o.out = View{S, (i + 1) * c_, c_};
+            e.ops.push_back(o);
+        }
+        conv(p + ".cv2", full(S), out, 1, 1, ACT_SILU);
+    }
+    void psa(const std::string& p, View in, View out) {
+        const int c = in.C / 2, sd = sdiv_of(in);
+        const int nh = c / 64, hd = c / nh, kd = hd / 2;
+        const int P = tensor(p + ".cv1", 2 * c, sd);
+        conv(p + ".cv1", in, full(P), 1, 1, ACT_SILU);
+        const View a{P, 0, c}, b{P, c, c};
+        (void)a;
+        const int Q = tensor(p + ".attn.qkv", c + 2 * kd * nh, sd);
+        conv(p + ".attn.qkv", b, full(Q), 1, 1, ACT_NONE);
+        const int O = tensor(p + ".attn.o", c, sd);
+        {
+            Op o;
+            o.kind = OP_ATTN; o.name = p + ".attn.o"; o.in = full(Q); o.out = full(O); o.nh = nh; o.kd = kd; o.hd = hd;
+            e.ops.push_back(o);
+        }
+        // o + pe(v): depthwise 3x3 over the v rows of qkv (channel h*hd+d lives at h*(2kd+hd)+2kd+d)
+        const int Y = tensor(p + ".attn.pe", c, sd);
+        dwconv(p + ".attn.pe", View{Q, 2 * kd, c}, full(Y), 3, 1, ACT_NONE, full(O), hd, 2 * kd + hd);
+        const int B1 = tensor(p + ".attn.proj", c, sd);
+        conv(p + ".attn.proj", full(Y), full(B1), 1, 1, ACT_NONE, b);      // b = b + attn(b)
+        const int F = tensor(p + ".ffn.0", 2 * c, sd);
+        conv(p + ".ffn.0", full(B1), full(F), 1, 1, ACT_SILU);
+        conv(p + ".ffn.1", full(F), b, 1, 1, ACT_NONE, full(B1));           // b = b + ffn(b), written over the dead b
+        conv(p + ".cv2", full(P), out, 1, 1, ACT_SILU);
+    }
+    void upsample(const std::string& name, View in, View out) {
+        Op o;
+        o.kind = OP_UPSAMPLE; o.name = name; o.in = in; o.out = out;
+        e.ops.push_back(o);
+    }
+};
+
+static int build_graph(yp_engine& e) {
+    Scale sc;
+    if (!variant_scale(e.desc.variant, sc)) return fail(YP_ERR_ARG, "unknown variant '%c'", e.desc.variant);
+    const int v = e.desc.variant;
+    Builder B(e);
+    auto C = [&](int c) { return make_div8(std::min(c, sc.maxc) * sc.width); };
+    auto N = [&](int n) { return n > 1 ? std::max(py_round(n * sc.depth), 1) : n; };
+
+    // resolved output channels of layers 0..22 (A.3)
+    const int c0 = C(64), c1 = C(128), c2 = C(128), c3 = C(256), c4 = C(256), c5 = C(512), c6 = C(512), c7 = C(1024),
+              c8 = C(1024), c9 = C(1024), c10 = C(1024), c13 = C(512), c16 = C(256), c17 = C(256), c19 = C(512),
+              c20 = C(512), c22 = C(1024);
+    // concat buffers, created up front so producers write straight into their slice
+    const int T12 = B.tensor("model.12", c10 + c6, 16);   // [up(L10), L6]
+    const int T15 = B.tensor("model.15", c13 + c4, 8);    // [up(L13), L4]
+    const int T18 = B.tensor("model.18", c17 + c13, 16);  // [L17, L13]
+    const int T21 = B.tensor("model.21", c20 + c10, 32);  // [L20, L10]
+    const View o4{T15, c13, c4}, o6{T12, c10, c6}, o13{T18, c17, c13}, o10{T21, c20, c10};
+
+    // L0 stem
+    const int t0 = B.tensor("model.0", c0, 2);
+    {
+        Op o;
+        o.kind = OP_STEM; o.name = "model.0"; o.out = B.full(t0); o.k = 3; o.s = 2; o.act = ACT_SILU;
+        o.widx = B.weight("model.0", c0, 3, 3, 1, false, true);
+        e.ops.push_back(o);
+    }
+    const int t1 = B.tensor("model.1", c1, 4);
+    B.conv("model.1", B.full(t0), B.full(t1), 3, 2, ACT_SILU);
+    const int t2 = B.tensor("model.2", c2, 4);
+    B.c2f("model.2", B.full(t1), B.full(t2), c2, N(3), true, false, false);
+    const int t3 = B.tensor("model.3", c3, 8);
+    B.conv("model.3", B.full(t2), B.full(t3), 3, 2, ACT_SILU);
+    B.c2f("model.4", B.full(t3), o4, c4, N(6), true, false, false);
+    const int t5 = B.tensor("model.5", c5, 16);
+    B.scdown("model.5", o4, B.full(t5));
+    B.c2f("model.6", B.full(t5), o6, c6, N(6), true, v == 'x', false);
+    const int t7 = B.tensor("model.7", c7, 32);
+    B.scdown("model.7", o6, B.full(t7));
+    const int t8 = B.tensor("model.8", c8, 32);
+    B.c2f("model.8", B.full(t7), B.full(t8), c8, N(3), true, v != 'n', v == 's');
+    const int t9 = B.tensor("model.9", c9, 32);
+    B.sppf("model.9", B.full(t8), B.full(t9));
+    B.psa("model.10", B.full(t9), o10);
+    B.upsample("model.11", o10, View{T12, 0, c10});
+    {
+        const bool cib = !(v == 'n' || v == 's' || v == 'm');
+        B.c2f("model.13", B.full(T12), o13, c13, N(3), cib, cib, false);
+    }
+    B.upsample("model.14", o13, View{T15, 0, c13});
+    const int t16 = B.tensor("model.16", c16, 8);
+    B.c2f("model.16", B.full(T15), B.full(t16), c16, N(3), false, false, false);
+    B.conv("model.17", B.full(t16), View{T18, 0, c17}, 3, 2, ACT_SILU);
+    const int t19 = B.tensor("model.19", c19, 16);
+    {
+        const bool cib = !(v == 'n' || v == 's');
+        B.c2f("model.19", B.full(T18), B.full(t19), c19, N(3), cib, cib, false);
+    }
+    B.scdown("model.20", B.full(t19), View{T21, 0, c20});
+    const int t22 = B.tensor("model.22", c22, 32);
+    B.c2f("model.22", B.full(T21), B.full(t22), c22, N(3), true, true, (v == 'n' || v == 's'));
+
+    // ---- v10Detect one-to-one head (A.4) (+ seg branches, A.7) ---------------------------------------
+    const int nc = e.desc.nc;
+    const View feat[3] = {B.full(t16), B.full(t19), B.full(t22)};
+    const int hc2 = std::max(std::max(16, feat[0].C / 4), 64);
+    const int hc3 = std::max(feat[0].C, std::min(nc, 100));
+    const int hc4 = std::max(feat[0].C / 4, YP_NM);
+    Op head;
+    head.kind = OP_HEAD; head.name = "model.23.postprocess"; head.nlev = 3;
+    for (int l = 0; l < 3; ++l) {
+        const std::string L = std::to_string(l);
+        const int sd = 8 << l;
+        const View x = feat[l];
+        const std::string pb = "model.23.one2one_cv2." + L, pc = "model.23.one2one_cv3." + L;
+        const int b0 = B.tensor(pb + ".0", hc2, sd), b1 = B.tensor(pb + ".1", hc2, sd), b2 = B.tensor(pb + ".2", 64, sd, true);
+        B.conv(pb + ".0", x, B.full(b0), 3, 1, ACT_SILU);
+        B.conv(pb + ".1", B.full(b0), B.full(b1), 3, 1, ACT_SILU);
+        B.conv(pb + ".2", B.full(b1), B.full(b2), 1, 1, ACT_NONE);
+        const int k0 = B.tensor(pc + ".0.0", x.C, sd), k1 = B.tensor(pc + ".0.1", hc3, sd), k2 = B.tensor(pc + ".1.0", hc3, sd),
+                  k3 = B.tensor(pc + ".1.1", hc3, sd), k4 = B.tensor(pc + ".2", nc, sd, true);
+        B.dwconv(pc + ".0.0", x, B.full(k0), 3, 1, ACT_SILU);
+        B.conv(pc + ".0.1", B.full(k0), B.full(k1), 1, 1, ACT_SILU);
+        B.dwconv(pc + ".1.0", B.full(k1), B.full(k2), 3, 1, ACT_SILU);
+        B.conv(pc + ".1.1", B.full(k2), B.full(k3), 1, 1, ACT_SILU);
+        B.conv(pc + ".2", B.full(k3), B.full(k4), 1, 1, ACT_NONE);
+        head.box[l] = B.full(b2);
+        head.cls[l] = B.full(k4);
+        if (e.desc.task == YP_TASK_SEGMENT) {
+            const std::string pm = "model.23.cv4." + L;
+            const int m0 = B.tensor(pm + ".0", hc4, sd), m1 = B.tensor(pm + ".1", hc4, sd), m2 = B.tensor(pm + ".2", YP_NM, sd, true);
+            B.conv(pm + ".0", x, B.full(m0), 3, 1, ACT_SILU);
+            B.conv(pm + ".1", B.full(m0), B.full(m1), 3, 1, ACT_SILU);
+            B.conv(pm + ".2", B.full(m1), B.full(m2), 1, 1, ACT_NONE);
+            head.cf[l] = B.full(m2);
+        }
+    }
+    if (e.desc.task == YP_TASK_SEGMENT) {
+        const int npr = feat[0].C;
+        const std::string pp = "model.23.proto";
+        const int p0 = B.tensor(pp + ".cv1", npr, 8), p1 = B.tensor(pp + ".upsample", npr, 4), p2 = B.tensor(pp + ".cv2", npr, 4),
+                  p3 = B.tensor(pp + ".cv3", YP_NM, 4);
+        B.conv(pp + ".cv1", feat[0], B.full(p0), 3, 1, ACT_SILU);
+        {
+            Op o;
+            o.kind = OP_CONVT; o.name = pp + ".upsample"; o.in = B.full(p0); o.out = B.full(p1); o.k = 2; o.s = 2; o.act = ACT_NONE;
+            o.widx = B.weight(pp + ".upsample", npr, npr, 2, 1, true);
+            e.ops.push_back(o);
+        }
+        B.conv(pp + ".cv2", B.full(p1), B.full(p2), 3, 1, ACT_SILU);
+        B.conv(pp + ".cv3", B.full(p2), B.full(p3), 1, 1, ACT_SILU);
+        e.proto_t = p3;
+    }
+    e.ops.push_back(head);
+    // the final 1x1 of each head branch emits fp32 logits
+    return YP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// plan: resolve shapes for (B,H,W), compute algorithmic flops/bytes
+// ---------------------------------------------------------------------------------------------------------
+static size_t tensor_elem_bytes(const yp_engine& e, const TensorDesc& t) { return (t.f32 || e.dtype == DT_F32) ? 4 : 2; }
+
+static int make_plan(yp_engine& e, int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0 || (H % 32) || (W % 32)) return fail(YP_ERR_ARG, "input must be [B,H,W,3] with H,W multiples of 32 (got %d,%d,%d)", B, H, W);
+    if (e.planned && e.pB == B && e.pH == H && e.pW == W) return YP_OK;
+    size_t A = 0;
+    for (int l = 0; l < 3; ++l) A += (size_t)(H / (8 << l)) * (W / (8 << l));
+    if (A > 16384) return fail(YP_ERR_ARG, "input %dx%d has %zu anchors; the LDS top-k supports at most 16384", H, W, A);
+    for (auto& t : e.tensors) {
+        t.H = H / t.sdiv; t.W = W / t.sdiv;
+        t.bytes = (size_t)B * t.H * t.W * t.C * tensor_elem_bytes(e, t);
+    }
+    for (auto& o : e.ops) {
+        const double es = e.es();
+        auto vbytes = [&](const View& v) {
+            if (v.t < 0) return 0.0;
+            const TensorDesc& t = e.tensors[v.t];
+            return (double)B * t.H * t.W * v.C * (double)tensor_elem_bytes(e, t);
+        };
+        o.flops = 0; o.bytes = vbytes(o.in) + vbytes(o.out) + vbytes(o.res);
+        if (o.kind == OP_CONV || o.kind == OP_DWCONV || o.kind == OP_STEM || o.kind == OP_CONVT) {
+            const TensorDesc& to = e.tensors[o.out.t];
+            const WeightDesc& w = e.weights[o.widx];
+            const double px = (double)B * to.H * to.W;
+            if (o.kind == OP_CONVT) o.flops = 2.0 * px * w.cout * w.cin_g;   // one tap per output pixel
+            else o.flops = 2.0 * px * w.cout * w.cin_g * w.k * w.k;
+            o.bytes += (double)w.cout * w.cin_g * w.k * w.k * es;
+            if (o.kind == OP_STEM) o.bytes += (double)B * H * W * 3;
+        } else if (o.kind == OP_ATTN) {
+            const TensorDesc& ti = e.tensors[o.in.t];
+            const double Nn = (double)ti.H * ti.W;
+            o.flops = 2.0 * B * o.nh * Nn * Nn * (o.kd + o.hd);
+        } else if (o.kind == OP_HEAD) {
+            o.bytes = 0;
+            for (int l = 0; l < 3; ++l) o.bytes += vbytes(o.cls[l]);
+            o.bytes += (double)B * e.desc.max_det * (6 + 1) * 4;
+        }
+    }
+    e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
+    return YP_OK;
+}
+
+static int allocate_plan(yp_engine& e) {
+    if (e.allocated) return YP_OK;
+    size_t total = 0;
+    for (auto& t : e.tensors) total += (t.bytes + 255) & ~(size_t)255;
+    HIPCHK(hipSetDevice(e.device));
+    if (total > e.arena_bytes) {
+        if (e.arena) HIPCHK(hipFree(e.arena));
+        e.arena = nullptr;
+        HIPCHK(hipMalloc(&e.arena, total));
+        e.arena_bytes = total;
+    }
+    size_t off = 0;
+    for (auto& t : e.tensors) {
+        t.ptr = (char*)e.arena + off;
+        off += (t.bytes + 255) & ~(size_t)255;
+    }
+    if (e.gexec) { (void)hipGraphExecDestroy(e.gexec); e.gexec = nullptr; }
+    e.allocated = true;
+    return YP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// op launch
+// ---------------------------------------------------------------------------------------------------------
+struct RunArgs { const uint8_t* in; float* det; int32_t* idx; float* coeff; };
+
+static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_t st) {
+    auto T = [&](const View& v) -> const TensorDesc& { return e.tensors[v.t]; };
+    const int B = e.pB;
+    switch (o.kind) {
+        case OP_STEM: {
+            const WeightDesc& w = e.weights[o.widx];
+            const TensorDesc& to = T(o.out);
+            StemParams p{};
+            p.x = a.in; p.H = e.pH; p.W = e.pW; p.w = (const float*)w.d_w; p.bias = w.d_b;
+            p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = to.H; p.Wo = to.W; p.C0 = o.out.C; p.B = B; p.act = o.act;
+            return launch_stem(p, e.dtype, st);
+        }
+        case OP_CONV: {
+            const WeightDesc& w = e.weights[o.widx];
+            const TensorDesc &ti = T(o.in), &to = T(o.out);
+            ConvParams p{};
+            p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.H = ti.H; p.W = ti.W; p.Cin = o.in.C;
+            p.w = w.d_w; p.Kpad = w.Kpad; p.bias = w.d_b;
+            p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = to.H; p.Wo = to.W; p.Cout = o.out.C;
+            if (o.res.t >= 0) { p.res = T(o.res).ptr; p.res_stride = T(o.res).C; p.res_coff = o.res.coff; }
+            p.M = B * to.H * to.W; p.ks = o.k; p.stride = o.s; p.pad = o.k / 2; p.act = o.act;
+            p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
+            p.up = 1; p.oy = 0; p.ox = 0;
+            return launch_conv(p, e.dtype, st);
+        }
+        case OP_CONVT: {
+            const WeightDesc& w = e.weights[o.widx];
+            const TensorDesc &ti = T(o.in), &to = T(o.out);
+            for (int dy = 0; dy < 2; ++dy)
+                for (int dx = 0; dx < 2; ++dx) {
+                    ConvParams p{};
+                    p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.H = ti.H; p.W = ti.W; p.Cin = o.in.C;
+                    const size_t sub = (size_t)((w.cout + 127) / 128 * 128) * w.Kpad * e.es();
+                    p.w = (const char*)w.d_w + sub * (dy * 2 + dx); p.Kpad = w.Kpad; p.bias = w.d_b;
+                    p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = ti.H; p.Wo = ti.W; p.Cout = o.out.C;
+                    p.M = B * ti.H * ti.W; p.ks = 1; p.stride = 1; p.pad = 0; p.act = o.act; p.out_f32 = 0;
+                    p.up = 2; p.oy = dy; p.ox = dx;
+                    hipError_t err = launch_conv(p, e.dtype, st);
+                    if (err != hipSuccess) return err;
+                }
+            return hipSuccess;
+        }
+        case OP_DWCONV: {
+            const WeightDesc& w = e.weights[o.widx];
+            const TensorDesc &ti = T(o.in), &to = T(o.out);
+            DwParams p{};
+            p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.H = ti.H; p.W = ti.W; p.C = o.out.C;
+            p.w = w.d_w; p.bias = w.d_b;
+            p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = to.H; p.Wo = to.W;
+            if (o.res.t >= 0) { p.res = T(o.res).ptr; p.res_stride = T(o.res).C; p.res_coff = o.res.coff; }
+            p.B = B; p.ks = o.k; p.stride = o.s; p.pad = o.k / 2; p.act = o.act; p.gs = o.gs; p.gstride = o.gstride;
+            return launch_dwconv(p, e.dtype, st);
+        }
+        case OP_POOL5: {
+            const TensorDesc &ti = T(o.in), &to = T(o.out);
+            PoolParams p{};
+            p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff;
+            p.B = B; p.H = ti.H; p.W = ti.W; p.C = o.in.C;
+            return launch_pool5(p, e.dtype, st);
+        }
+        case OP_UPSAMPLE: {
+            const TensorDesc &ti = T(o.in), &to = T(o.out);
+            UpParams p{};
+            p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff;
+            p.B = B; p.H = ti.H; p.W = ti.W; p.C = o.in.C;
+            return launch_upsample(p, e.dtype, st);
+        }
+        case OP_ATTN: {
+            const TensorDesc &ti = T(o.in), &to = T(o.out);
+            AttnParams p{};
+            p.qkv = ti.ptr; p.q_stride = ti.C; p.q_coff = o.in.coff; p.o = to.ptr; p.o_stride = to.C; p.o_coff = o.out.coff;
+            p.B = B; p.N = ti.H * ti.W; p.nh = o.nh; p.kd = o.kd; p.hd = o.hd; p.scale = 1.0f / std::sqrt((float)o.kd);
+            return launch_attention(p, e.dtype, st);
+        }
+        case OP_HEAD: {
+            HeadParams p{};
+            p.nlev = 3; p.A = 0;
+            for (int l = 0; l < 3; ++l) {
+                const TensorDesc& tb = T(o.box[l]);
+                p.box[l] = (const float*)tb.ptr; p.cls[l] = (const float*)T(o.cls[l]).ptr;
+                p.cf[l] = (o.cf[l].t >= 0) ? (const float*)T(o.cf[l]).ptr : nullptr;
+                p.hw[l][0] = tb.H; p.hw[l][1] = tb.W; p.A += tb.H * tb.W;
+            }
+            p.B = B; p.nc = e.desc.nc; p.max_det = e.desc.max_det;
+            p.det = a.det; p.idx = a.idx; p.coeff = (o.cf[0].t >= 0) ? a.coeff : nullptr;
+            return launch_head(p, st);
+        }
+    }
+    return hipErrorInvalidValue;
+}
+
+static int run_all(yp_engine& e, const RunArgs& a, hipStream_t st) {
+    for (const Op& o : e.ops) {
+        hipError_t err = run_op(e, o, a, st);
+        if (err != hipSuccess) return fail(YP_ERR_HIP, "launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
+    }
+    return YP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------------------
+static void put(std::vector<unsigned char>& buf, size_t idx, float v, int dtype) {
+    if (dtype == DT_BF16) { uint16_t h = f2bf(v); memcpy(&buf[idx * 2], &h, 2); }
+    else memcpy(&buf[idx * 4], &v, 4);
+}
+
+static int upload_weight(yp_engine& e, WeightDesc& w) {
+    const int es = e.es();
+    std::vector<unsigned char> buf;
+    if (w.is_stem) {
+        // [ky][kx][c_bgr][co] fp32, values rounded to the engine dtype; BGR memory order <- RGB weight order
+        std::vector<float> f((size_t)27 * w.cout);
+        for (int co = 0; co < w.cout; ++co)
+            for (int ci = 0; ci < 3; ++ci)
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        float v = w.w[((size_t)(co * 3 + ci) * 3 + ky) * 3 + kx];
+                        if (e.dtype == DT_BF16) v = bf2f(f2bf(v));
+                        f[((size_t)(ky * 3 + kx) * 3 + (2 - ci)) * w.cout + co] = v;
+                    }
+        HIPCHK(hipMalloc(&w.d_w, f.size() * 4));
+        HIPCHK(hipMemcpy(w.d_w, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+    } else if (w.groups > 1) {
+        // depthwise: [k*k][C]
+        const int C = w.cout, kk = w.k * w.k;
+        buf.assign((size_t)kk * C * es, 0);
+        for (int c = 0; c < C; ++c)
+            for (int t = 0; t < kk; ++t) put(buf, (size_t)t * C + c, w.w[(size_t)c * kk + t], e.dtype);
+        HIPCHK(hipMalloc(&w.d_w, buf.size()));
+        HIPCHK(hipMemcpy(w.d_w, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    } else if (w.transposed) {
+        // ConvTranspose2d k2 s2: weight [Cin][Cout][2][2] -> 4 GEMM matrices [CoutPad][Kpad], K = Cin
+        const int cin = w.cin_g, cout = w.cout;
+        w.Kpad = (cin + 31) / 32 * 32;
+        const size_t rows = (size_t)(cout + 127) / 128 * 128, sub = rows * w.Kpad;
+        buf.assign(sub * 4 * es, 0);
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx)
+                for (int co = 0; co < cout; ++co)
+                    for (int ci = 0; ci < cin; ++ci)
+                        put(buf, sub * (dy * 2 + dx) + (size_t)co * w.Kpad + ci, w.w[(((size_t)ci * cout + co) * 2 + dy) * 2 + dx], e.dtype);
+        HIPCHK(hipMalloc(&w.d_w, buf.size()));
+        HIPCHK(hipMemcpy(w.d_w, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    } else {
+        // dense: [Cout][Cin][k][k] -> [CoutPad128][Kpad], k order (ky,kx,ci)
+        const int cin = w.cin_g, cout = w.cout, k = w.k;
+        const int K = k * k * cin;
+        w.Kpad = (K + 31) / 32 * 32;
+        const size_t rows = (size_t)(cout + 127) / 128 * 128;
+        buf.assign(rows * w.Kpad * es, 0);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int ky = 0; ky < k; ++ky)
+                    for (int kx = 0; kx < k; ++kx)
+                        put(buf, (size_t)co * w.Kpad + (size_t)(ky * k + kx) * cin + ci, w.w[(((size_t)co * cin + ci) * k + ky) * k + kx], e.dtype);
+        HIPCHK(hipMalloc(&w.d_w, buf.size()));
+        HIPCHK(hipMemcpy(w.d_w, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMalloc((void**)&w.d_b, (size_t)w.cout * 4));
+    HIPCHK(hipMemcpy(w.d_b, w.b.data(), (size_t)w.cout * 4, hipMemcpyHostToDevice));
+    std::vector<float>().swap(w.w);
+    return YP_OK;
+}
+
+static void weight_shape(const WeightDesc& w, int64_t s[4]) {
+    if (w.transposed) { s[0] = w.cin_g; s[1] = w.cout; }
+    else { s[0] = w.cout; s[1] = w.cin_g; }
+    s[2] = w.k; s[3] = w.k;
+}
+
+}  // namespace
+
+// =========================================================================================================
+// C-ABI
+// =========================================================================================================
+extern "C" {
+
+const char* yp_last_error(void) { return g_err; }
+
+int yp_create(const yp_model_desc* desc, int device, yp_engine** out) {
+    if (!desc || !out) return fail(YP_ERR_ARG, "null argument");
+    if (desc->nc <= 0 || desc->max_det <= 0 || desc->max_det > 1024) return fail(YP_ERR_ARG, "bad nc/max_det");
+    if (desc->dtype != YP_BF16 && desc->dtype != YP_F32) return fail(YP_ERR_ARG, "bad dtype");
+    if (desc->task != YP_TASK_DETECT && desc->task != YP_TASK_SEGMENT) return fail(YP_ERR_ARG, "bad task");
+    std::unique_ptr<yp_engine> e(new yp_engine());
+    e->desc = *desc; e->device = device; e->dtype = desc->dtype;
+    int rc = build_graph(*e);
+    if (rc != YP_OK) return rc;
+    for (const Op& o : e->ops)
+        for (const View* v : {&o.in, &o.out, &o.res})
+            if (v->t >= 0 && o.kind != OP_STEM && ((v->C & 7) || (v->coff & 7)) && !e->tensors[v->t].f32)
+                return fail(YP_ERR_ARG, "op %s: channel slice (%d,%d) is not a multiple of 8", o.name.c_str(), v->coff, v->C);
+    *out = e.release();
+    return YP_OK;
+}
+
+int yp_destroy(yp_engine* e) {
+    if (!e) return YP_OK;
+    if (e->finalized || e->arena) (void)hipSetDevice(e->device);
+    for (auto& w : e->weights) { if (w.d_w) (void)hipFree(w.d_w); if (w.d_b) (void)hipFree(w.d_b); }
+    if (e->arena) (void)hipFree(e->arena);
+    if (e->mask_ws) (void)hipFree(e->mask_ws);
+    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+    return YP_OK;
+}
+
+int yp_weight_count(const yp_engine* e) { return e ? (int)e->weights.size() * 2 : fail(YP_ERR_ARG, "null engine"); }
+
+int yp_weight_info(const yp_engine* e, int i, char* name, int cap, int64_t shape[4], int* ndim) {
+    if (!e || i < 0 || i >= (int)e->weights.size() * 2) return fail(YP_ERR_ARG, "bad weight index");
+    const WeightDesc& w = e->weights[i / 2];
+    const bool is_bias = i & 1;
+    if (name && cap > 0) snprintf(name, cap, "%s.%s", w.name.c_str(), is_bias ? "bias" : "weight");
+    if (is_bias) { if (shape) { shape[0] = w.cout; shape[1] = shape[2] = shape[3] = 1; } if (ndim) *ndim = 1; }
+    else { if (shape) weight_shape(w, shape); if (ndim) *ndim = 4; }
+    return YP_OK;
+}
+
+int yp_set_weight(yp_engine* e, const char* name, const float* host, const int64_t* shape, int ndim) {
+    if (!e || !name || !host || !shape) return fail(YP_ERR_ARG, "null argument");
+    if (e->finalized) return fail(YP_ERR_STATE, "engine already finalized");
+    std::string n(name);
+    const bool is_bias = n.size() > 5 && n.compare(n.size() - 5, 5, ".bias") == 0;
+    const bool is_w = n.size() > 7 && n.compare(n.size() - 7, 7, ".weight") == 0;
+    if (!is_bias && !is_w) return fail(YP_ERR_WEIGHT, "parameter name '%s' must end in .weight or .bias", name);
+    const std::string base = n.substr(0, n.size() - (is_bias ? 5 : 7));
+    auto it = e->wmap.find(base);
+    if (it == e->wmap.end()) return fail(YP_ERR_WEIGHT, "unknown parameter '%s'", name);
+    WeightDesc& w = e->weights[it->second];
+    if (is_bias) {
+        if (ndim != 1 || shape[0] != w.cout) return fail(YP_ERR_WEIGHT, "'%s': expected shape [%d]", name, w.cout);
+        w.b.assign(host, host + w.cout);
+        w.have_b = true;
+    } else {
+        int64_t s[4];
+        weight_shape(w, s);
+        if (ndim != 4 || shape[0] != s[0] || shape[1] != s[1] || shape[2] != s[2] || shape[3] != s[3])
+            return fail(YP_ERR_WEIGHT, "'%s': expected shape [%lld,%lld,%lld,%lld]", name, (long long)s[0], (long long)s[1], (long long)s[2], (long long)s[3]);
+        w.w.assign(host, host + (size_t)(s[0] * s[1] * s[2] * s[3]));
+        w.have_w = true;
+    }
+    return YP_OK;
+}
+
+int yp_finalize(yp_engine* e) {
+    if (!e) return fail(YP_ERR_ARG, "null engine");
+    if (e->finalized) return YP_OK;
+    for (const auto& w : e->weights)
+        if (!w.have_w || !w.have_b) return fail(YP_ERR_WEIGHT, "parameter '%s.%s' was never set", w.name.c_str(), w.have_w ? "bias" : "weight");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(YP_ERR_HIP, "no HIP device: the MI355X kernels cannot run here (no CPU fallback exists)");
+    if (e->device < 0 || e->device >= ndev) return fail(YP_ERR_ARG, "device %d out of range (%d devices)", e->device, ndev);
+    HIPCHK(hipSetDevice(e->device));
+    for (auto& w : e->weights) {
+        int rc = upload_weight(*e, w);
+        if (rc != YP_OK) return rc;
+    }
+    HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    e->finalized = true;
+    return YP_OK;
+}
+
+int yp_plan(yp_engine* e, int B, int H, int W) {
+    if (!e) return fail(YP_ERR_ARG, "null engine");
+    int rc = make_plan(*e, B, H, W);
+    return rc == YP_OK ? (int)e->ops.size() : rc;
+}
+
+int yp_op_info(const yp_engine* e, int i, char* name, int cap, int* kind, double* flops, double* bytes) {
+    if (!e || i < 0 || i >= (int)e->ops.size()) return fail(YP_ERR_ARG, "bad op index");
+    const Op& o = e->ops[i];
+    if (name && cap > 0) snprintf(name, cap, "%s", o.name.c_str());
+    if (kind) *kind = o.kind;
+    if (flops) *flops = o.flops;
+    if (bytes) *bytes = o.bytes;
+    return YP_OK;
+}
+
+int yp_op_output(const yp_engine* e, int i, int* tensor, int* coff, int* C) {
+    if (!e || i < 0 || i >= (int)e->ops.size()) return fail(YP_ERR_ARG, "bad op index");
+    const Op& o = e->ops[i];
+    if (tensor) *tensor = o.out.t;
+    if (coff) *coff = o.out.coff;
+    if (C) *C = o.out.C;
+    return YP_OK;
+}
+
+int yp_tensor_count(const yp_engine* e) { return e ? (int)e->tensors.size() : fail(YP_ERR_ARG, "null engine"); }
+
+int yp_tensor_info(const yp_engine* e, int i, char* name, int cap, int dims[4], int* is_f32) {
+    if (!e || i < 0 || i >= (int)e->tensors.size()) return fail(YP_ERR_ARG, "bad tensor index");
+    const TensorDesc& t = e->tensors[i];
+    if (name && cap > 0) snprintf(name, cap, "%s", t.name.c_str());
+    if (dims) { dims[0] = e->pB; dims[1] = t.H; dims[2] = t.W; dims[3] = t.C; }
+    if (is_f32) *is_f32 = (t.f32 || e->dtype == DT_F32) ? 1 : 0;
+    return YP_OK;
+}
+
+int yp_tensor_read(yp_engine* e, int i, float* host_out) {
+    if (!e || i < 0 || i >= (int)e->tensors.size() || !host_out) return fail(YP_ERR_ARG, "bad argument");
+    if (!e->allocated) return fail(YP_ERR_STATE, "no forward has run yet");
+    const TensorDesc& t = e->tensors[i];
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t n = (size_t)e->pB * t.H * t.W * t.C;
+    if (t.f32 || e->dtype == DT_F32) {
+        HIPCHK(hipMemcpy(host_out, t.ptr, n * 4, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<uint16_t> tmp(n);
+        HIPCHK(hipMemcpy(tmp.data(), t.ptr, n * 2, hipMemcpyDeviceToHost));
+        for (size_t j = 0; j < n; ++j) host_out[j] = bf2f(tmp[j]);
+    }
+    return YP_OK;
+}
+
+static int prepare(yp_engine* e, int B, int H, int W, const uint8_t* in, float* det) {
+    if (!e || !in || !det) return fail(YP_ERR_ARG, "null argument");
+    if (!e->finalized) return fail(YP_ERR_STATE, "yp_finalize has not been called");
+    int rc = make_plan(*e, B, H, W);
+    if (rc != YP_OK) return rc;
+    return allocate_plan(*e);
+}
+
+int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
+               float* coeff_out, void* stream) {
+    int rc = prepare(e, B, H, W, in_dev, det_out);
+    if (rc != YP_OK) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    RunArgs a{in_dev, det_out, idx_out, coeff_out};
+    if (!e->use_graph) return run_all(*e, a, st);
+
+    // hipGraph replay on the engine's own stream, ordered against the caller's stream by events
+    yp_engine::Key k{B, H, W, in_dev, det_out, idx_out, coeff_out};
+    if (!e->gexec || memcmp(&k, &e->gkey, sizeof(k)) != 0) {
+        if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
+        rc = run_all(*e, a, e->own_stream);
+        hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
+        if (rc != YP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (ce != hipSuccess) return fail(YP_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        HIPCHK(hipGraphInstantiate(&e->gexec, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        e->gkey = k;
+    }
+    HIPCHK(hipEventRecord(e->ev_in, st));
+    HIPCHK(hipStreamWaitEvent(e->own_stream, e->ev_in, 0));
+    HIPCHK(hipGraphLaunch(e->gexec, e->own_stream));
+    HIPCHK(hipEventRecord(e->ev_out, e->own_stream));
+    HIPCHK(hipStreamWaitEvent(st, e->ev_out, 0));
+    return YP_OK;
+}
+
+int yp_set_graph(yp_engine* e, int enable) {
+    if (!e) return fail(YP_ERR_ARG, "null engine");
+    e->use_graph = enable != 0;
+    return YP_OK;
+}
+
+int yp_profile(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
+               float* coeff_out, float* ms_out, int iters, void* stream) {
+    int rc = prepare(e, B, H, W, in_dev, det_out);
+    if (rc != YP_OK) return rc;
+    if (!ms_out || iters <= 0) return fail(YP_ERR_ARG, "bad profile arguments");
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    RunArgs a{in_dev, det_out, idx_out, coeff_out};
+    const size_t n = e->ops.size();
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+    std::vector<double> acc(n, 0.0);
+    for (int it = 0; it < iters; ++it) {
+        for (size_t i = 0; i < n; ++i) {
+            HIPCHK(hipEventRecord(ev[2 * i], st));
+            hipError_t err = run_op(*e, e->ops[i], a, st);
+            if (err != hipSuccess) return fail(YP_ERR_HIP, "op %s: %s", e->ops[i].name.c_str(), hipGetErrorString(err));
+            HIPCHK(hipEventRecord(ev[2 * i + 1], st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        for (size_t i = 0; i < n; ++i) {
+            float ms = 0;
+            HIPCHK(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+            acc[i] += ms;
+        }
+    }
+    for (size_t i = 0; i < n; ++i) ms_out[i] = (float)(acc[i] / iters);
+    for (auto& x : ev) (void)hipEventDestroy(x);
+    return YP_OK;
+}
+
+int yp_proto(const yp_engine* e, const void** proto_dev, int* Hp, int* Wp) {
+    if (!e || !proto_dev) return fail(YP_ERR_ARG, "null argument");
+    if (e->proto_t < 0) return fail(YP_ERR_STATE, "engine was not created with YP_TASK_SEGMENT");
+    if (!e->allocated) return fail(YP_ERR_STATE, "no forward has run yet");
+    const TensorDesc& t = e->tensors[e->proto_t];
+    *proto_dev = t.ptr;
+    if (Hp) *Hp = t.H;
+    if (Wp) *Wp = t.W;
+    return YP_OK;
+}
+
+int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev, int n, int oh, int ow, int retina,
+             uint8_t* masks_out, int64_t* id_out, int32_t* kept_out, int suppress_small, int min_area, void* stream) {
+    if (!e) return fail(YP_ERR_ARG, "null engine");
+    if (e->proto_t < 0) return fail(YP_ERR_STATE, "engine was not created with YP_TASK_SEGMENT");
+    if (!e->allocated) return fail(YP_ERR_STATE, "no forward has run yet");
+    if (b < 0 || b >= e->pB || n < 0 || oh <= 0 || ow <= 0) return fail(YP_ERR_ARG, "bad mask arguments");
+    if (!retina && (oh != e->pH || ow != e->pW)) return fail(YP_ERR_ARG, "retina=0 masks are produced at the letterboxed input size %dx%d", e->pH, e->pW);
+    if (kept_out && !id_out) return fail(YP_ERR_ARG, "kept_out needs id_out");
+    HIPCHK(hipSetDevice(e->device));
+    const TensorDesc& t = e->tensors[e->proto_t];
+    MaskParams p{};
+    p.proto = (const char*)t.ptr + (size_t)b * t.H * t.W * t.C * tensor_elem_bytes(*e, t);
+    p.Hp = t.H; p.Wp = t.W; p.coeff = coeff_dev; p.boxes = boxes_dev; p.n = n; p.oh = oh; p.ow = ow;
+    if (retina) {
+        // scale_masks (A.7): gain=min(mh/oh,mw/ow); pad=((mw-ow*gain)/2,(mh-oh*gain)/2); crop [int(pad):int(m-pad)]
+        const double gain = std::min((double)t.H / oh, (double)t.W / ow);
+        const double padw = (t.W - ow * gain) / 2, padh = (t.H - oh * gain) / 2;
+        p.t = (int)padh; p.l = (int)padw;
+        p.ch = (int)(t.H - padh) - p.t; p.cw = (int)(t.W - padw) - p.l;
+        p.bsx = 1.f; p.bsy = 1.f; p.crop_before = 0;
+    } else {
+        p.t = 0; p.l = 0; p.ch = t.H; p.cw = t.W;
+        p.bsx = (float)t.W / (float)e->pW; p.bsy = (float)t.H / (float)e->pH; p.crop_before = 1;
+    }
+    p.masks = masks_out; p.ids = id_out; p.kept = kept_out; p.suppress_small = suppress_small; p.min_area = min_area;
+    {
+        const size_t need = 2 * (size_t)((n + 3) & ~3) * 4 + (size_t)n * p.ch * p.cw * 4 + (masks_out ? 0 : (size_t)n * oh * ow) + 256;
+        if (need > e->mask_ws_bytes) {
+            HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+            if (e->mask_ws) HIPCHK(hipFree(e->mask_ws));
+            e->mask_ws = nullptr;
+            HIPCHK(hipMalloc(&e->mask_ws, need));
+            e->mask_ws_bytes = need;
+        }
+        p.area = (int32_t*)e->mask_ws;
+    }
+    hipError_t err = launch_masks(p, e->dtype, (hipStream_t)stream);
+    if (err != hipSuccess) return fail(YP_ERR_HIP, "mask kernels: %s", hipGetErrorString(err));
+    return YP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,242 @@
+"""ctypes binding of libyolop.so (include/yolop.h). Tensors in / tensors out; PyTorch is only the owner of device
+memory and streams. There is NO fallback: if the HIP library is missing or no GPU is present, calls raise.
+
+Replaces what `ultralytics.YOLO(path)` builds and what `.predict` runs (reference yolo_seg/app.py:45,91).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .weights import fold_state
+
+_LIB: Optional[C.CDLL] = None
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolop.so")
+
+YP_BF16, YP_F32 = 0, 1
+TASK_DETECT, TASK_SEGMENT = 0, 1
+OP_KINDS = {0: "stem", 1: "conv", 2: "dwconv", 3: "pool5", 4: "upsample", 5: "attn", 6: "head", 7: "convT"}
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("variant", C.c_int), ("nc", C.c_int), ("task", C.c_int), ("dtype", C.c_int), ("max_det", C.c_int)]
+
+
+class YolopError(RuntimeError):
+    pass
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """dlopen libyolop.so and declare the prototypes of include/yolop.h. Raises if it was not built."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or LIB_PATH
+    if not os.path.isfile(p):
+        raise YolopError(f"{p} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                         f"(hipcc --offload-arch=gfx950). There is no CPU fallback for the hot path.")
+    lib = C.CDLL(p)
+    vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_float)
+    lib.yp_last_error.restype = C.c_char_p
+    lib.yp_create.argtypes = [C.POINTER(ModelDesc), C.c_int, C.POINTER(vp)]
+    lib.yp_destroy.argtypes = [vp]
+    lib.yp_weight_count.argtypes = [vp]
+    lib.yp_weight_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), ip]
+    lib.yp_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int]
+    lib.yp_finalize.argtypes = [vp]
+    lib.yp_forward.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.yp_proto.argtypes = [vp, C.POINTER(vp), ip, ip]
+    lib.yp_masks.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.yp_plan.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    lib.yp_op_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.yp_op_output.argtypes = [vp, C.c_int, ip, ip, ip]
+    lib.yp_tensor_count.argtypes = [vp]
+    lib.yp_tensor_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, ip, ip]
+    lib.yp_tensor_read.argtypes = [vp, C.c_int, vp]
+    lib.yp_profile.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]
+    lib.yp_set_graph.argtypes = [vp, C.c_int]
+    for fn in ("yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight", "yp_finalize",
+               "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output", "yp_tensor_count",
+               "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph"):
+        getattr(lib, fn).restype = C.c_int
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
+           "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output",
+           "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph"]
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Engine:
+    """One engine per GPU. `state` is an (unfused) ultralytics-layout state dict; see weights.py."""
+
+    def __init__(self, variant: str = "s", nc: int = 80, seg: bool = False, dtype: str = "bf16",
+                 device: int = 0, max_det: int = 300, state: Optional[Dict[str, torch.Tensor]] = None,
+                 finalize: bool = True):
+        self.lib = load_library()
+        self.variant, self.nc, self.seg, self.max_det = variant, nc, seg, max_det
+        self.dtype = {"bf16": YP_BF16, "fp32": YP_F32, "f32": YP_F32}[dtype]
+        self.device_index = int(device)
+        self._h = C.c_void_p()
+        desc = ModelDesc(ord(variant), nc, TASK_SEGMENT if seg else TASK_DETECT, self.dtype, max_det)
+        self._chk(self.lib.yp_create(C.byref(desc), self.device_index, C.byref(self._h)))
+        self._keep: List[torch.Tensor] = []
+        self.finalized = False
+        if state is not None:
+            self.load_state(state)
+            if finalize:
+                self.finalize()
+
+    # -- errors ------------------------------------------------------------------------------------------------
+    def _chk(self, rc: int) -> int:
+        if rc < 0:
+            raise YolopError(f"libyolop error {rc}: {self.lib.yp_last_error().decode()}")
+        return rc
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.yp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights -----------------------------------------------------------------------------------------------
+    def expected_weights(self) -> List[Tuple[str, Tuple[int, ...]]]:
+        out = []
+        n = self._chk(self.lib.yp_weight_count(self._h))
+        name = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int()
+        for i in range(n):
+            self._chk(self.lib.yp_weight_info(self._h, i, name, 256, shape, C.byref(nd)))
+            out.append((name.value.decode(), tuple(int(shape[j]) for j in range(nd.value))))
+        return out
+
+    def load_state(self, state: Dict[str, torch.Tensor]) -> None:
+        """Fold Conv+BN (and merge RepVGGDW) on the host, hand every folded fp32 tensor to the engine."""
+        folded = fold_state(state)
+        for name, (w, b) in folded.items():
+            for suffix, t in ((".weight", w), (".bias", b)):
+                t = t.detach().to(torch.float32).contiguous().cpu()
+                shp = (C.c_int64 * t.dim())(*t.shape)
+                self._chk(self.lib.yp_set_weight(self._h, (name + suffix).encode(), C.c_void_p(t.data_ptr()), shp, t.dim()))
+
+    def finalize(self) -> None:
+        self._chk(self.lib.yp_finalize(self._h))
+        self.finalized = True
+
+    def set_graph(self, enable: bool) -> None:
+        self._chk(self.lib.yp_set_graph(self._h, 1 if enable else 0))
+
+    # -- hot path ------------------------------------------------------------------------------------------------
+    def forward(self, im: torch.Tensor, out: Optional[dict] = None) -> dict:
+        """im: uint8 cuda tensor [B,H,W,3] BGR, letterboxed (H,W multiples of 32).
+        -> dict(det [B,max_det,6] f32, idx [B,max_det] i32, coeff [B,max_det,32] f32 | None)."""
+        if not im.is_cuda or im.dtype != torch.uint8 or im.dim() != 4 or im.shape[-1] != 3:
+            raise TypeError("forward expects a uint8 CUDA tensor [B,H,W,3]")
+        if im.device.index != self.device_index:
+            raise ValueError(f"input is on cuda:{im.device.index}, engine on cuda:{self.device_index}")
+        im = im.contiguous()
+        B, H, W, _ = im.shape
+        dev = im.device
+        if out is None:
+            out = dict(det=torch.empty((B, self.max_det, 6), dtype=torch.float32, device=dev),
+                       idx=torch.empty((B, self.max_det), dtype=torch.int32, device=dev),
+                       coeff=torch.empty((B, self.max_det, 32), dtype=torch.float32, device=dev) if self.seg else None)
+        cf = out["coeff"].data_ptr() if out.get("coeff") is not None else None
+        self._chk(self.lib.yp_forward(self._h, C.c_void_p(im.data_ptr()), B, H, W, C.c_void_p(out["det"].data_ptr()),
+                                      C.c_void_p(out["idx"].data_ptr()), C.c_void_p(cf), C.c_void_p(_stream_ptr(dev))))
+        self._last_im = im    # keep the input alive until the stream has consumed it
+        return out
+
+    def proto(self) -> torch.Tensor:
+        """Engine-owned prototypes of the last forward as fp32 [B,Hp,Wp,32] (a copy; test/debug helper)."""
+        t = self.find_tensor("model.23.proto.cv3")
+        return self.read_tensor(t)
+
+    def masks(self, b: int, coeff: torch.Tensor, boxes: torch.Tensor, out_hw: Tuple[int, int], retina: bool = True,
+              want_masks: bool = True, want_ids: bool = False, suppress_small: bool = False, min_area: int = 100):
+        """-> (masks uint8 [n,oh,ow] | None, ids int64 [oh,ow] | None, kept int32 [n] | None)"""
+        n = int(coeff.shape[0])
+        dev = coeff.device
+        oh, ow = int(out_hw[0]), int(out_hw[1])
+        coeff = coeff.to(torch.float32).contiguous()
+        boxes = boxes.to(torch.float32).contiguous()
+        m = torch.empty((n, oh, ow), dtype=torch.uint8, device=dev) if want_masks else None
+        ids = torch.empty((oh, ow), dtype=torch.int64, device=dev) if want_ids else None
+        kept = torch.empty((n,), dtype=torch.int32, device=dev) if want_ids else None
+        self._chk(self.lib.yp_masks(self._h, b, C.c_void_p(coeff.data_ptr()), C.c_void_p(boxes.data_ptr()), n, oh, ow,
+                                    1 if retina else 0, C.c_void_p(m.data_ptr() if m is not None else None),
+                                    C.c_void_p(ids.data_ptr() if ids is not None else None),
+                                    C.c_void_p(kept.data_ptr() if kept is not None else None),
+                                    1 if suppress_small else 0, int(min_area), C.c_void_p(_stream_ptr(dev))))
+        self._keep = [coeff, boxes]
+        return m, ids, kept
+
+    # -- introspection ---------------------------------------------------------------------------------------------
+    def plan(self, B: int, H: int, W: int) -> List[dict]:
+        n = self._chk(self.lib.yp_plan(self._h, B, H, W))
+        ops = []
+        name = C.create_string_buffer(256)
+        kind, fl, by = C.c_int(), C.c_double(), C.c_double()
+        t, co, cc = C.c_int(), C.c_int(), C.c_int()
+        for i in range(n):
+            self._chk(self.lib.yp_op_info(self._h, i, name, 256, C.byref(kind), C.byref(fl), C.byref(by)))
+            self._chk(self.lib.yp_op_output(self._h, i, C.byref(t), C.byref(co), C.byref(cc)))
+            ops.append(dict(name=name.value.decode(), kind=OP_KINDS[kind.value], flops=fl.value, bytes=by.value,
+                            out=(t.value, co.value, cc.value)))
+        return ops
+
+    def tensors(self) -> List[dict]:
+        n = self._chk(self.lib.yp_tensor_count(self._h))
+        name = C.create_string_buffer(256)
+        dims = (C.c_int * 4)()
+        f32 = C.c_int()
+        out = []
+        for i in range(n):
+            self._chk(self.lib.yp_tensor_info(self._h, i, name, 256, dims, C.byref(f32)))
+            out.append(dict(index=i, name=name.value.decode(), shape=tuple(dims), f32=bool(f32.value)))
+        return out
+
+    def find_tensor(self, name: str) -> int:
+        for t in self.tensors():
+            if t["name"] == name:
+                return t["index"]
+        raise KeyError(name)
+
+    def read_tensor(self, index: int) -> torch.Tensor:
+        """Debug tap: NHWC fp32 host copy of an engine-owned activation of the last forward."""
+        info = self.tensors()[index]
+        out = torch.empty(info["shape"], dtype=torch.float32)
+        self._chk(self.lib.yp_tensor_read(self._h, index, C.c_void_p(out.data_ptr())))
+        return out
+
+    def profile(self, im: torch.Tensor, iters: int = 5) -> List[dict]:
+        """Per-op HIP-event timing (eager, one event pair per launch) on the current stream."""
+        B, H, W, _ = im.shape
+        ops = self.plan(B, H, W)
+        dev = im.device
+        det = torch.empty((B, self.max_det, 6), dtype=torch.float32, device=dev)
+        idx = torch.empty((B, self.max_det), dtype=torch.int32, device=dev)
+        cf = torch.empty((B, self.max_det, 32), dtype=torch.float32, device=dev) if self.seg else None
+        ms = (C.c_float * len(ops))()
+        self._chk(self.lib.yp_profile(self._h, C.c_void_p(im.data_ptr()), B, H, W, C.c_void_p(det.data_ptr()),
+                                      C.c_void_p(idx.data_ptr()), C.c_void_p(cf.data_ptr() if cf is not None else None),
+                                      ms, iters, C.c_void_p(_stream_ptr(dev))))
+        for o, m in zip(ops, ms):
+            o["ms"] = float(m)
+        return ops
