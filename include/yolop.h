@@ -96,6 +96,10 @@ int yp_plan(yp_engine* e, int B, int H, int W);            /* (re)build the plan
 int yp_op_info(const yp_engine* e, int i, char* name, int name_cap, int* kind, double* flops,
                double* bytes);                                 /* algorithmic FLOPs / HBM bytes of op i */
 int yp_op_output(const yp_engine* e, int i, int* tensor, int* coff, int* C); /* output channel slice of op i (tensor<0: user buffers) */
+/* Debug stepping for per-op parity tests ("teacher forcing"): run ONE op of the current plan, and overwrite a
+ * channel slice of an engine tensor from fp32 host data [B,H,W,C] (converted to the tensor's storage type). */
+int yp_run_op(yp_engine* e, int i, const uint8_t* in_dev, float* det_out, int32_t* idx_out, float* coeff_out, void* stream);
+int yp_tensor_write(yp_engine* e, int tensor, int coff, int C, const float* host);
 int yp_tensor_count(const yp_engine* e);
 int yp_tensor_info(const yp_engine* e, int i, char* name, int name_cap, int dims[4] /*B,H,W,C*/, int* is_f32);
 int yp_tensor_read(yp_engine* e, int i, float* host_out);  /* sync copy NHWC -> fp32 host (debug taps) */

@@ -673,6 +673,37 @@ int yp_op_output(const yp_engine* e, int i, int* tensor, int* coff, int* C) {
     return YP_OK;
 }
 
+int yp_run_op(yp_engine* e, int i, const uint8_t* in_dev, float* det_out, int32_t* idx_out, float* coeff_out, void* stream) {
+    if (!e || i < 0 || i >= (int)e->ops.size()) return fail(YP_ERR_ARG, "bad op index");
+    if (!e->allocated) return fail(YP_ERR_STATE, "no forward has run yet");
+    HIPCHK(hipSetDevice(e->device));
+    RunArgs a{in_dev, det_out, idx_out, coeff_out};
+    hipError_t err = run_op(*e, e->ops[i], a, (hipStream_t)stream);
+    if (err != hipSuccess) return fail(YP_ERR_HIP, "op %s: %s", e->ops[i].name.c_str(), hipGetErrorString(err));
+    return YP_OK;
+}
+
+int yp_tensor_write(yp_engine* e, int ti, int coff, int C, const float* host) {
+    if (!e || ti < 0 || ti >= (int)e->tensors.size() || !host) return fail(YP_ERR_ARG, "bad argument");
+    if (!e->allocated) return fail(YP_ERR_STATE, "no forward has run yet");
+    const TensorDesc& t = e->tensors[ti];
+    if (coff < 0 || C <= 0 || coff + C > t.C) return fail(YP_ERR_ARG, "bad channel slice");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    const size_t npix = (size_t)e->pB * t.H * t.W;
+    const size_t es = tensor_elem_bytes(*e, t);
+    std::vector<unsigned char> buf(npix * t.C * es);
+    HIPCHK(hipMemcpy(buf.data(), t.ptr, buf.size(), hipMemcpyDeviceToHost));
+    for (size_t p = 0; p < npix; ++p)
+        for (int c = 0; c < C; ++c) {
+            const float v = host[p * C + c];
+            if (es == 4) memcpy(&buf[(p * t.C + coff + c) * 4], &v, 4);
+            else { const uint16_t h = f2bf(v); memcpy(&buf[(p * t.C + coff + c) * 2], &h, 2); }
+        }
+    HIPCHK(hipMemcpy(t.ptr, buf.data(), buf.size(), hipMemcpyHostToDevice));
+    return YP_OK;
+}
+
 int yp_tensor_count(const yp_engine* e) { return e ? (int)e->tensors.size() : fail(YP_ERR_ARG, "null engine"); }
 
 int yp_tensor_info(const yp_engine* e, int i, char* name, int cap, int dims[4], int* is_f32) {

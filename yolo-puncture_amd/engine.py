@@ -54,6 +54,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_plan.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.yp_op_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.yp_op_output.argtypes = [vp, C.c_int, ip, ip, ip]
+    lib.yp_run_op.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    lib.yp_tensor_write.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.yp_tensor_count.argtypes = [vp]
     lib.yp_tensor_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, ip, ip]
     lib.yp_tensor_read.argtypes = [vp, C.c_int, vp]
@@ -61,7 +63,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_set_graph.argtypes = [vp, C.c_int]
     for fn in ("yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight", "yp_finalize",
                "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output", "yp_tensor_count",
-               "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph"):
+               "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op", "yp_tensor_write"):
         getattr(lib, fn).restype = C.c_int
     if path is None:
         _LIB = lib
@@ -70,7 +72,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output",
-           "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph"]
+           "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
+           "yp_tensor_write"]
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -224,6 +227,17 @@ class Engine:
         out = torch.empty(info["shape"], dtype=torch.float32)
         self._chk(self.lib.yp_tensor_read(self._h, index, C.c_void_p(out.data_ptr())))
         return out
+
+    def run_op(self, i: int, im: torch.Tensor, out: dict) -> None:
+        """Debug stepping: launch op i of the current plan (inputs are whatever the engine tensors hold)."""
+        cf = out["coeff"].data_ptr() if out.get("coeff") is not None else None
+        self._chk(self.lib.yp_run_op(self._h, i, C.c_void_p(im.data_ptr()), C.c_void_p(out["det"].data_ptr()),
+                                     C.c_void_p(out["idx"].data_ptr()), C.c_void_p(cf), C.c_void_p(_stream_ptr(im.device))))
+
+    def write_tensor(self, index: int, coff: int, data_nhwc: torch.Tensor) -> None:
+        """Debug: overwrite channels [coff, coff+C) of an engine tensor from an fp32 host tensor [B,H,W,C]."""
+        d = data_nhwc.detach().to(torch.float32).contiguous().cpu()
+        self._chk(self.lib.yp_tensor_write(self._h, index, coff, int(d.shape[-1]), C.c_void_p(d.data_ptr())))
 
     def profile(self, im: torch.Tensor, iters: int = 5) -> List[dict]:
         """Per-op HIP-event timing (eager, one event pair per launch) on the current stream."""
