@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py - images/sec of the YOLOv10-S 640x640 bs=32 predict hot path on N MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of 32 synthetic 640x640 uint8 BGR frames per GPU that are
+already resident in HBM: stem (u8->bf16, /255, BGR->RGB) -> backbone -> neck -> one-to-one head -> DFL decode ->
+two-stage top-k -> [32,300,6]; at N>1 followed by the single RCCL all-gather of the detections. Frames are
+sharded across ranks (weak scaling: 32 frames per GPU). Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+PEAK_BF16_TFLOPS = 2500.0   # dense bf16 MFMA
+PEAK_F32_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="frames per GPU per step (BASELINE config: 32)")
+    ap.add_argument("--variant", default="s")
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--seg", action="store_true", help="config 5: S-seg trunk + proto (mask tail not in the step)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the bounded CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(variant: str, seg: bool, imgsz: int, frames: int):
+    """The oracle (torch-CPU fp32 restatement of the reference's path; the reference's own `ultralytics` path
+    cannot be installed) timed on this box's host cores on a bounded sample of the same workload."""
+    from oracle.yolov10_oracle import Oracle
+    from yolo_puncture_amd.weights import synthetic_state
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    st = synthetic_state(variant, 80, seg, seed=0)
+    orc = Oracle(st, variant, 80, seg, "fp32")
+    g = torch.Generator().manual_seed(0)
+    im = torch.randint(0, 256, (frames, imgsz, imgsz, 3), dtype=torch.uint8, generator=g)
+    with torch.no_grad():
+        orc.forward(im[:2])                       # warm-up (oneDNN primitive creation)
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            orc.forward(im)
+            reps += 1
+            dt = time.perf_counter() - t0
+            if dt > 10.0 or reps >= 5:
+                break
+    return dict(value=round(frames * reps / dt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle fp32 (torch-CPU), YOLOv10-{variant.upper()} {imgsz}x{imgsz}, {frames} frames x {reps} passes, "
+                       f"one-to-one head only; host reports {cores} cpus")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
+
+    from yolo_puncture_amd.engine import Engine
+    from yolo_puncture_amd.weights import synthetic_state
+
+    B, S = a.batch, a.imgsz
+    st = synthetic_state(a.variant, 80, a.seg, seed=0)         # seeded synthetic weights (no checkpoint offline)
+    eng = Engine(a.variant, 80, a.seg, a.dtype, local, state=st)
+    g = torch.Generator().manual_seed(rank)                    # rank r holds frames [r*B, (r+1)*B)
+    frames = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).to(dev)
+    out = dict(det=torch.empty((B, 300, 6), dtype=torch.float32, device=dev),
+               idx=torch.empty((B, 300), dtype=torch.int32, device=dev),
+               coeff=torch.empty((B, 300, 32), dtype=torch.float32, device=dev) if a.seg else None)
+    gathered = torch.empty((world * B, 300, 6), dtype=torch.float32, device=dev) if world > 1 else None
+    eng.set_graph(not a.no_graph)
+
+    def step():
+        eng.forward(frames, out)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, out["det"])
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / a.steps * 1e3
+    value = world * B * a.steps / dt
+
+    roof = None
+    if rank == 0 and not a.no_roofline:
+        # per-op HIP event pairs on the launch stream (eager replay of the same plan), after the timed region
+        eng.set_graph(False)
+        prof = eng.profile(frames, iters=5)
+        by_kernel = {}
+        for o in prof:
+            k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+            k["ms"] += o["ms"]; k["flops"] += o["flops"]; k["bytes"] += o["bytes"]; k["n"] += 1
+        total_ms = sum(k["ms"] for k in by_kernel.values())
+        dom = max(by_kernel, key=lambda n: by_kernel[n]["ms"])
+        d = by_kernel[dom]
+        ai = d["flops"] / max(d["bytes"], 1.0)
+        peak_tf = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+        ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+        avg_ms = d["ms"] / d["n"]
+        if ai >= ridge:
+            ach = d["flops"] / d["n"] / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak_tf, unit="TFLOP/s", frac=round(ach / peak_tf, 4), traffic=None)
+        else:
+            ach = d["bytes"] / d["n"] / (avg_ms * 1e-3) / 1e9
+            roof = dict(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), traffic=None)
+        roof.update(kernel=dom, launches_per_step=d["n"], avg_launch_ms=round(avg_ms, 5),
+                    alg_bytes_per_launch=round(d["bytes"] / d["n"]), alg_flops_per_launch=round(d["flops"] / d["n"]),
+                    flop_per_byte=round(ai, 1), tflops=round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
+                    share_of_step=round(d["ms"] / total_ms, 3), eager_step_ms=round(total_ms, 3),
+                    kernels={n: dict(ms=round(v["ms"], 4), n=v["n"], tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                                     gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)) for n, v in by_kernel.items()})
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.variant, a.seg, S, a.cpu_frames)
+
+    if rank == 0:
+        line = {
+            "metric": "images/sec", "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"YOLOv10-{a.variant.upper()}{'-seg' if a.seg else ''} {S}x{S} bs={B}/GPU {a.dtype}, "
+                                   f"u8 frames resident in HBM -> [B,300,6] detections"
+                                   + (", RCCL all-gather of detections" if world > 1 else ""),
+                       "global_batch": world * B, "imgsz": S, "parallelism": f"frame-shard x{world}",
+                       "weights": "seeded synthetic (SURVEY 8d)", "hipgraph": not a.no_graph},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -95,6 +95,7 @@ int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev
 int yp_plan(yp_engine* e, int B, int H, int W);            /* (re)build the plan; returns #ops or <0 */
 int yp_op_info(const yp_engine* e, int i, char* name, int name_cap, int* kind, double* flops,
                double* bytes);                                 /* algorithmic FLOPs / HBM bytes of op i */
+int yp_op_kernel(const yp_engine* e, int i, char* name, int name_cap);   /* device kernel symbol op i launches */
 int yp_op_output(const yp_engine* e, int i, int* tensor, int* coff, int* C); /* output channel slice of op i (tensor<0: user buffers) */
 /* Debug stepping for per-op parity tests ("teacher forcing"): run ONE op of the current plan, and overwrite a
  * channel slice of an engine tensor from fp32 host data [B,H,W,C] (converted to the tensor's storage type). */

@@ -75,8 +75,10 @@ def test_layerwise_fp32(variant, seg, shape):
 
 
 def _ulps_bf16(got, want):
-    """difference in units of the bf16 spacing at |want| (2^-7 of the leading power of two; floor 2^-133)."""
-    mag = want.abs().clamp_min(2.0 ** -126)
+    """difference in units of the bf16 spacing at |want| (2^-7 of the leading power of two). The magnitude is
+    floored at 2^-10 of the tensor's max: a result that cancels to ~0 still carries the fp32 summation noise of
+    its O(max) terms (~1e-6*max), which is many 'ulps' of a tiny value but is not a rounding disagreement."""
+    mag = want.abs().clamp_min(float(want.abs().max()) * 2.0 ** -10 + 2.0 ** -126)
     ulp = torch.exp2(torch.floor(torch.log2(mag)) - 7)
     return (got - want).abs() / ulp
 

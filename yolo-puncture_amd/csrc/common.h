@@ -63,6 +63,7 @@ struct Op {
     View box[3], cls[3], cf[3];   // head inputs per level
     int nlev = 0;
     double flops = 0, bytes = 0;  // algorithmic (filled by the plan)
+    std::string kernel;           // device kernel symbol this op launches (filled by the plan)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -127,6 +128,7 @@ struct HeadParams {
 
 // launches (implemented in the .hip files); dtype selects the template instance
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st);
+const char* conv_kernel_name(const ConvParams& p, int dtype);
 hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st);
 hipError_t launch_pool5(const PoolParams& p, int dtype, hipStream_t st);

@@ -310,6 +310,7 @@ static int build_graph(yp_engine& e) {
 // ---------------------------------------------------------------------------------------------------------
 // plan: resolve shapes for (B,H,W), compute algorithmic flops/bytes
 // ---------------------------------------------------------------------------------------------------------
+static ConvParams conv_params(const yp_engine& e, const Op& o);
 static size_t tensor_elem_bytes(const yp_engine& e, const TensorDesc& t) { return (t.f32 || e.dtype == DT_F32) ? 4 : 2; }
 
 static int make_plan(yp_engine& e, int B, int H, int W) {
@@ -349,6 +350,15 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         }
     }
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
+    static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_topk_kernel", ""};
+    for (auto& o : e.ops) {
+        if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
+        else if (o.kind == OP_CONVT) {
+            ConvParams p{};
+            p.Cout = o.out.C; p.M = B * e.tensors[o.in.t].H * e.tensors[o.in.t].W;
+            o.kernel = conv_kernel_name(p, e.dtype);
+        } else o.kernel = kn[o.kind];
+    }
     return YP_OK;
 }
 
@@ -378,6 +388,20 @@ static int allocate_plan(yp_engine& e) {
 // ---------------------------------------------------------------------------------------------------------
 struct RunArgs { const uint8_t* in; float* det; int32_t* idx; float* coeff; };
 
+static ConvParams conv_params(const yp_engine& e, const Op& o) {
+    const WeightDesc& w = e.weights[o.widx];
+    const TensorDesc &ti = e.tensors[o.in.t], &to = e.tensors[o.out.t];
+    ConvParams p{};
+    p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.H = ti.H; p.W = ti.W; p.Cin = o.in.C;
+    p.w = w.d_w; p.Kpad = w.Kpad; p.bias = w.d_b;
+    p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = to.H; p.Wo = to.W; p.Cout = o.out.C;
+    if (o.res.t >= 0) { p.res = e.tensors[o.res.t].ptr; p.res_stride = e.tensors[o.res.t].C; p.res_coff = o.res.coff; }
+    p.M = e.pB * to.H * to.W; p.ks = o.k; p.stride = o.s; p.pad = o.k / 2; p.act = o.act;
+    p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
+    p.up = 1; p.oy = 0; p.ox = 0;
+    return p;
+}
+
 static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_t st) {
     auto T = [&](const View& v) -> const TensorDesc& { return e.tensors[v.t]; };
     const int B = e.pB;
@@ -390,19 +414,8 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = to.H; p.Wo = to.W; p.C0 = o.out.C; p.B = B; p.act = o.act;
             return launch_stem(p, e.dtype, st);
         }
-        case OP_CONV: {
-            const WeightDesc& w = e.weights[o.widx];
-            const TensorDesc &ti = T(o.in), &to = T(o.out);
-            ConvParams p{};
-            p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.H = ti.H; p.W = ti.W; p.Cin = o.in.C;
-            p.w = w.d_w; p.Kpad = w.Kpad; p.bias = w.d_b;
-            p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = to.H; p.Wo = to.W; p.Cout = o.out.C;
-            if (o.res.t >= 0) { p.res = T(o.res).ptr; p.res_stride = T(o.res).C; p.res_coff = o.res.coff; }
-            p.M = B * to.H * to.W; p.ks = o.k; p.stride = o.s; p.pad = o.k / 2; p.act = o.act;
-            p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
-            p.up = 1; p.oy = 0; p.ox = 0;
-            return launch_conv(p, e.dtype, st);
-        }
+        case OP_CONV:
+            return launch_conv(conv_params(e, o), e.dtype, st);
         case OP_CONVT: {
             const WeightDesc& w = e.weights[o.widx];
             const TensorDesc &ti = T(o.in), &to = T(o.out);
@@ -661,6 +674,12 @@ int yp_op_info(const yp_engine* e, int i, char* name, int cap, int* kind, double
     if (kind) *kind = o.kind;
     if (flops) *flops = o.flops;
     if (bytes) *bytes = o.bytes;
+    return YP_OK;
+}
+
+int yp_op_kernel(const yp_engine* e, int i, char* name, int cap) {
+    if (!e || i < 0 || i >= (int)e->ops.size() || !name || cap <= 0) return fail(YP_ERR_ARG, "bad argument");
+    snprintf(name, cap, "%s", e->ops[i].kernel.c_str());
     return YP_OK;
 }
 

@@ -54,6 +54,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_plan.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.yp_op_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.yp_op_output.argtypes = [vp, C.c_int, ip, ip, ip]
+    lib.yp_op_kernel.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
     lib.yp_run_op.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     lib.yp_tensor_write.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.yp_tensor_count.argtypes = [vp]
@@ -63,7 +64,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_set_graph.argtypes = [vp, C.c_int]
     for fn in ("yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight", "yp_finalize",
                "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output", "yp_tensor_count",
-               "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op", "yp_tensor_write"):
+               "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op", "yp_tensor_write",
+               "yp_op_kernel"):
         getattr(lib, fn).restype = C.c_int
     if path is None:
         _LIB = lib
@@ -73,7 +75,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write"]
+           "yp_tensor_write", "yp_op_kernel"]
 
 
 def _stream_ptr(device: torch.device) -> int:
@@ -200,8 +202,11 @@ class Engine:
         for i in range(n):
             self._chk(self.lib.yp_op_info(self._h, i, name, 256, C.byref(kind), C.byref(fl), C.byref(by)))
             self._chk(self.lib.yp_op_output(self._h, i, C.byref(t), C.byref(co), C.byref(cc)))
-            ops.append(dict(name=name.value.decode(), kind=OP_KINDS[kind.value], flops=fl.value, bytes=by.value,
-                            out=(t.value, co.value, cc.value)))
+            rec = dict(name=name.value.decode(), kind=OP_KINDS[kind.value], flops=fl.value, bytes=by.value,
+                       out=(t.value, co.value, cc.value))
+            self._chk(self.lib.yp_op_kernel(self._h, i, name, 256))
+            rec["kernel"] = name.value.decode()
+            ops.append(rec)
         return ops
 
     def tensors(self) -> List[dict]:
