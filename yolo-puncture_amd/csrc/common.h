@@ -50,6 +50,7 @@ struct WeightDesc {
     void* d_w = nullptr;       // layout depends on the consumer kernel
     float* d_b = nullptr;
     int Kpad = 0;
+    size_t mat_bytes = 0;      // bytes of one packed GEMM matrix
 };
 
 struct Op {
@@ -80,6 +81,7 @@ struct ConvParams {
     int ks, stride, pad;
     int act, out_f32;
     int up, oy, ox;                             // output pixel (ho,wo) -> (ho*up+oy, wo*up+ox) in an (Ho*up,Wo*up) image
+    size_t x_bytes, w_bytes;                    // extents of the x tensor / packed weight matrix (buffer descriptors)
 };
 
 struct DwParams {
@@ -129,6 +131,9 @@ struct HeadParams {
 // launches (implemented in the .hip files); dtype selects the template instance
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st);
 const char* conv_kernel_name(const ConvParams& p, int dtype);
+hipError_t launch_conv_dma(const ConvParams& p, hipStream_t st);
+bool conv_dma_supported(const ConvParams& p);
+const char* conv_dma_kernel_name(const ConvParams& p);
 hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st);
 hipError_t launch_pool5(const PoolParams& p, int dtype, hipStream_t st);

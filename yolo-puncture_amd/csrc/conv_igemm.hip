@@ -240,6 +240,7 @@ static int conv_tile_choice(const ConvParams& p) {
     return 2;
 }
 const char* conv_kernel_name(const ConvParams& p, int dtype) {
+    if (dtype == DT_BF16 && conv_dma_supported(p)) return conv_dma_kernel_name(p);
     static const char* names[2][3] = {
         {"conv_igemm_kernel<bf16,128,32,4,1>", "conv_igemm_kernel<bf16,128,64,2,2>", "conv_igemm_kernel<bf16,128,128,2,2>"},
         {"conv_igemm_kernel<f32,128,32,4,1>", "conv_igemm_kernel<f32,128,64,2,2>", "conv_igemm_kernel<f32,128,128,2,2>"}};
@@ -266,6 +267,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t st) {
 }
 
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st) {
+    if (dtype == DT_BF16 && conv_dma_supported(p)) return launch_conv_dma(p, st);
     if (dtype == DT_BF16) return launch_conv_t<__bf16>(p, st);
     return launch_conv_t<float>(p, st);
 }

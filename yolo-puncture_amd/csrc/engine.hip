@@ -355,7 +355,8 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
         else if (o.kind == OP_CONVT) {
             ConvParams p{};
-            p.Cout = o.out.C; p.M = B * e.tensors[o.in.t].H * e.tensors[o.in.t].W;
+            p.Cout = o.out.C; p.M = B * e.tensors[o.in.t].H * e.tensors[o.in.t].W; p.Cin = o.in.C; p.ks = 1;
+            p.Kpad = (o.in.C + 31) / 32 * 32;
             o.kernel = conv_kernel_name(p, e.dtype);
         } else o.kernel = kn[o.kind];
     }
@@ -399,6 +400,7 @@ static ConvParams conv_params(const yp_engine& e, const Op& o) {
     p.M = e.pB * to.H * to.W; p.ks = o.k; p.stride = o.s; p.pad = o.k / 2; p.act = o.act;
     p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
     p.up = 1; p.oy = 0; p.ox = 0;
+    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes;
     return p;
 }
 
@@ -428,6 +430,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
                     p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = ti.H; p.Wo = ti.W; p.Cout = o.out.C;
                     p.M = B * ti.H * ti.W; p.ks = 1; p.stride = 1; p.pad = 0; p.act = o.act; p.out_f32 = 0;
                     p.up = 2; p.oy = dy; p.ox = dx;
+                    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes;
                     hipError_t err = launch_conv(p, e.dtype, st);
                     if (err != hipSuccess) return err;
                 }
@@ -527,6 +530,7 @@ static int upload_weight(yp_engine& e, WeightDesc& w) {
         const int cin = w.cin_g, cout = w.cout;
         w.Kpad = (cin + 31) / 32 * 32;
         const size_t rows = (size_t)(cout + 127) / 128 * 128, sub = rows * w.Kpad;
+        w.mat_bytes = sub * es;
         buf.assign(sub * 4 * es, 0);
         for (int dy = 0; dy < 2; ++dy)
             for (int dx = 0; dx < 2; ++dx)
@@ -541,6 +545,7 @@ static int upload_weight(yp_engine& e, WeightDesc& w) {
         const int K = k * k * cin;
         w.Kpad = (K + 31) / 32 * 32;
         const size_t rows = (size_t)(cout + 127) / 128 * 128;
+        w.mat_bytes = rows * w.Kpad * es;
         buf.assign(rows * w.Kpad * es, 0);
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
