@@ -109,6 +109,12 @@ int yp_tensor_read(yp_engine* e, int i, float* host_out);  /* sync copy NHWC -> 
 int yp_profile(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
                float* coeff_out, float* ms_out, int iters, void* stream);
 
+/* Enable/disable the plan-time autotuner that picks the conv tile configuration per layer (default on). */
+int yp_set_autotune(yp_engine* e, int enable);
+
+/* Test hook: force conv tile configuration `cfg` wherever it is valid (-1 = off). Returns the number of configurations. */
+int yp_debug_force_conv_cfg(int cfg);
+
 /* Enable/disable hipGraph capture+replay of the forward (default on after the first eager run). */
 int yp_set_graph(yp_engine* e, int enable);
 

@@ -83,9 +83,10 @@ def _ulps_bf16(got, want):
     return (got - want).abs() / ulp
 
 
-@pytest.mark.parametrize("variant,seg,shape", [("n", True, (2, 96, 128)), ("s", False, (1, 160, 192)),
-                                               ("x", False, (1, 64, 64))])
-def test_per_op_bf16_teacher_forced(variant, seg, shape):
+@pytest.mark.parametrize("variant,seg,shape,cfg", [("n", True, (2, 96, 128), -1), ("s", False, (1, 160, 192), -1),
+                                                   ("x", False, (1, 64, 64), -1)] +
+                         [("s", True, (3, 96, 160), c) for c in range(14)])
+def test_per_op_bf16_teacher_forced(variant, seg, shape, cfg):
     """bf16 kernels one at a time: every op consumes the ORACLE's (bf16emu) tensors - after each op its output
     slice is overwritten with the oracle's tap - so the only admissible difference is the bf16 rounding of an
     fp32 sum taken in a different order: <= 1 bf16 ulp per element, on a small fraction of the elements.
@@ -95,7 +96,11 @@ def test_per_op_bf16_teacher_forced(variant, seg, shape):
     st, im = make_case(variant, 80, seg, 0, shape)
     taps = {}
     Oracle(st, variant, 80, seg, "bf16emu", tap=lambda n, x: taps.__setitem__(n, x.float())).forward(im)
+    from yolo_puncture_amd.engine import load_library
+    assert load_library().yp_debug_force_conv_cfg(cfg) >= 14    # cfg >= 0: every conv that admits this tile config uses it
     eng = _engine(variant, 80, seg, "bf16", st)
+    if cfg >= 0:
+        eng.set_autotune(False)
     imc = im.cuda()
     out = eng.forward(imc)               # allocates the plan; results are recomputed op by op below
     torch.cuda.synchronize()
@@ -123,9 +128,10 @@ def test_per_op_bf16_teacher_forced(variant, seg, shape):
             assert frac < 0.02, (o["name"], frac)
         eng.write_tensor(t, c0, want)    # teacher forcing
     _dump(f"perop_bf16_{variant}", [(n, k, e) for n, k, e, _ in rows])
-    print(variant, "ops checked", len(rows), "max ulp", max(r[2] for r in rows if r[1] != "f32"),
+    print(variant, "cfg", cfg, "ops checked", len(rows), "max ulp", max(r[2] for r in rows if r[1] != "f32"),
           "max differing fraction", max(r[3] for r in rows))
     eng.close()
+    load_library().yp_debug_force_conv_cfg(-1)
     assert len(rows) > 50
 
 

@@ -65,6 +65,7 @@ struct Op {
     int nlev = 0;
     double flops = 0, bytes = 0;  // algorithmic (filled by the plan)
     std::string kernel;           // device kernel symbol this op launches (filled by the plan)
+    int cfg = -1;                 // autotuned conv_dma configuration (-1: heuristic)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -82,6 +83,7 @@ struct ConvParams {
     int act, out_f32;
     int up, oy, ox;                             // output pixel (ho,wo) -> (ho*up+oy, wo*up+ox) in an (Ho*up,Wo*up) image
     size_t x_bytes, w_bytes;                    // extents of the x tensor / packed weight matrix (buffer descriptors)
+    int cfg;                                    // conv_dma tile configuration (-1: heuristic)
 };
 
 struct DwParams {
@@ -134,6 +136,9 @@ const char* conv_kernel_name(const ConvParams& p, int dtype);
 hipError_t launch_conv_dma(const ConvParams& p, hipStream_t st);
 bool conv_dma_supported(const ConvParams& p);
 const char* conv_dma_kernel_name(const ConvParams& p);
+int conv_dma_num_cfgs();
+void conv_dma_force_cfg(int cfg);
+bool conv_dma_cfg_valid(const ConvParams& p, int cfg);
 hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st);
 hipError_t launch_pool5(const PoolParams& p, int dtype, hipStream_t st);

@@ -35,18 +35,19 @@ template <int BK> __device__ __forceinline__ int swz_mask(int row) {
 }
 
 template <int BM, int BN, int WGM, int WGN, int BK, int NS>
-__global__ __launch_bounds__(256) void conv_dma_kernel(const ConvParams p, const int mtiles, const int ntiles) {
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_kernel(const ConvParams p, const int mtiles, const int ntiles) {
+    constexpr int NW = WGM * WGN;             // waves per workgroup (4 or 8)
     constexpr int CPR = BK / 8;               // 16-B chunks per LDS row
     constexpr int RB = BK * 2;                // bytes per LDS row
     constexpr int A_INSTR = BM * CPR / 64;    // 1-KiB wave-instructions per stage for the pixel tile
     constexpr int W_INSTR = BN * CPR / 64;
-    constexpr int A_IPW = A_INSTR / 4;
-    constexpr int W_IPW = (W_INSTR + 3) / 4;
+    constexpr int A_IPW = A_INSTR / NW;
+    constexpr int W_IPW = (W_INSTR + NW - 1) / NW;
     constexpr int LPW = A_IPW + W_IPW;        // loads per wave per stage (uniform)
     constexpr int SB = (BM + BN) * RB;        // stage bytes
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
     constexpr int KSUB = BK / 32;
-    static_assert(WGM * WGN == 4 && A_INSTR % 4 == 0, "tile/wave layout");
+    static_assert((NW == 4 || NW == 8) && A_INSTR % NW == 0 && A_IPW >= 1, "tile/wave layout");
     constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];   // NS stages + 1 KiB dump slot
@@ -240,12 +241,45 @@ __global__ __launch_bounds__(256) void conv_dma_kernel(const ConvParams p, const
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// tile selection + launch
+// configurations + launch. p.cfg >= 0 selects one explicitly (the engine's plan-time autotuner times the valid ones
+// per layer and keeps the fastest); p.cfg < 0 uses the static heuristic.
 // ---------------------------------------------------------------------------------------------------------------
-struct DmaCfg { int id; const char* name; };
+struct DmaCfg { int BM, BN, NW, BK, NS; const char* name; };
+static const DmaCfg kCfgs[] = {
+    {128, 32, 4, 32, 4, "conv_dma_kernel<128,32,4,1,32,4>"},     // 0
+    {128, 64, 4, 32, 4, "conv_dma_kernel<128,64,2,2,32,4>"},     // 1
+    {128, 128, 4, 32, 4, "conv_dma_kernel<128,128,2,2,32,4>"},   // 2
+    {64, 64, 4, 32, 4, "conv_dma_kernel<64,64,2,2,32,4>"},       // 3
+    {256, 64, 8, 32, 4, "conv_dma_kernel<256,64,4,2,32,4>"},     // 4
+    {256, 128, 8, 32, 4, "conv_dma_kernel<256,128,4,2,32,4>"},   // 5
+    {256, 128, 8, 64, 3, "conv_dma_kernel<256,128,4,2,64,3>"},   // 6
+    {128, 128, 4, 64, 3, "conv_dma_kernel<128,128,2,2,64,3>"},   // 7
+    {128, 64, 4, 64, 3, "conv_dma_kernel<128,64,2,2,64,3>"},     // 8
+    {256, 64, 8, 64, 3, "conv_dma_kernel<256,64,4,2,64,3>"},     // 9
+    {128, 256, 8, 32, 4, "conv_dma_kernel<128,256,2,4,32,4>"},   // 10
+    {256, 32, 8, 32, 4, "conv_dma_kernel<256,32,8,1,32,4>"},     // 11
+    {128, 256, 8, 64, 3, "conv_dma_kernel<128,256,2,4,64,3>"},   // 12
+    {64, 128, 4, 64, 3, "conv_dma_kernel<64,128,2,2,64,3>"},     // 13
+};
+constexpr int kNumCfgs = (int)(sizeof(kCfgs) / sizeof(kCfgs[0]));
 
-static int dma_choice(const ConvParams& p) {
-    // 0: 128x32   1: 128x64   2: 128x128   3: 64x64   (BK=32, 4-deep ring for all)
+int conv_dma_num_cfgs() { return kNumCfgs; }
+
+bool conv_dma_supported(const ConvParams& p) {
+    return (p.Cin % 32) == 0 && (p.Kpad % 32) == 0 && p.x_bytes < (1ull << 31) && p.w_bytes < (1ull << 31) && p.ks <= 3;
+}
+
+bool conv_dma_cfg_valid(const ConvParams& p, int c) {
+    if (c < 0 || c >= kNumCfgs || !conv_dma_supported(p)) return false;
+    const DmaCfg& k = kCfgs[c];
+    if (k.BK == 64 && ((p.Cin % 64) != 0 || (p.Kpad % 64) != 0)) return false;
+    const int cpad = (p.Cout + 31) / 32 * 32;
+    if (k.BN > 32 && k.BN >= 2 * cpad) return false;            // more than half the tile would be padding
+    if (k.BN == 32 && p.Cout > 32) return false;
+    return true;
+}
+
+static int dma_heuristic(const ConvParams& p) {
     if (p.Cout <= 32) return 0;
     const long ctas128 = (long)((p.M + 127) / 128) * ((p.Cout + 127) / 128);
     if ((p.Cout % 128) == 0 && ctas128 >= 1024) return 2;
@@ -253,16 +287,14 @@ static int dma_choice(const ConvParams& p) {
     if (ctas64 >= 512) return 1;
     return 3;
 }
-
-bool conv_dma_supported(const ConvParams& p) {
-    return (p.Cin % 32) == 0 && (p.Kpad % 32) == 0 && p.x_bytes < (1ull << 31) && p.w_bytes < (1ull << 31) && p.ks <= 3;
+static int g_force_cfg = -1;   // debug/test override (yp_debug_force_conv_cfg)
+void conv_dma_force_cfg(int c) { g_force_cfg = c; }
+static int dma_choice(const ConvParams& p) {
+    if (conv_dma_cfg_valid(p, g_force_cfg)) return g_force_cfg;
+    return conv_dma_cfg_valid(p, p.cfg) ? p.cfg : dma_heuristic(p);
 }
 
-const char* conv_dma_kernel_name(const ConvParams& p) {
-    static const char* n[] = {"conv_dma_kernel<128,32,4,1,32,4>", "conv_dma_kernel<128,64,2,2,32,4>",
-                              "conv_dma_kernel<128,128,2,2,32,4>", "conv_dma_kernel<64,64,2,2,32,4>"};
-    return n[dma_choice(p)];
-}
+const char* conv_dma_kernel_name(const ConvParams& p) { return kCfgs[dma_choice(p)].name; }
 
 template <int BM, int BN, int WGM, int WGN, int BK, int NS>
 static hipError_t launch_one(const ConvParams& p, hipStream_t st) {
@@ -275,7 +307,7 @@ static hipError_t launch_one(const ConvParams& p, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(256), sh, st, p, mtiles, ntiles);
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(WGM * WGN * 64), sh, st, p, mtiles, ntiles);
     return hipGetLastError();
 }
 
@@ -284,7 +316,17 @@ hipError_t launch_conv_dma(const ConvParams& p, hipStream_t st) {
         case 0: return launch_one<128, 32, 4, 1, 32, 4>(p, st);
         case 1: return launch_one<128, 64, 2, 2, 32, 4>(p, st);
         case 2: return launch_one<128, 128, 2, 2, 32, 4>(p, st);
-        default: return launch_one<64, 64, 2, 2, 32, 4>(p, st);
+        case 3: return launch_one<64, 64, 2, 2, 32, 4>(p, st);
+        case 4: return launch_one<256, 64, 4, 2, 32, 4>(p, st);
+        case 5: return launch_one<256, 128, 4, 2, 32, 4>(p, st);
+        case 6: return launch_one<256, 128, 4, 2, 64, 3>(p, st);
+        case 7: return launch_one<128, 128, 2, 2, 64, 3>(p, st);
+        case 8: return launch_one<128, 64, 2, 2, 64, 3>(p, st);
+        case 9: return launch_one<256, 64, 4, 2, 64, 3>(p, st);
+        case 10: return launch_one<128, 256, 2, 4, 32, 4>(p, st);
+        case 11: return launch_one<256, 32, 8, 1, 32, 4>(p, st);
+        case 12: return launch_one<128, 256, 2, 4, 64, 3>(p, st);
+        default: return launch_one<64, 128, 2, 2, 64, 3>(p, st);
     }
 }
 

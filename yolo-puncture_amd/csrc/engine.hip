@@ -49,6 +49,7 @@ struct yp_engine {
     size_t mask_ws_bytes = 0;
     // hipGraph replay
     bool use_graph = false;
+    bool tune = true;             // plan-time autotuning of the conv tile configuration
     hipStream_t own_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -350,13 +351,14 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         }
     }
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
+    for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_topk_kernel", ""};
     for (auto& o : e.ops) {
         if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
         else if (o.kind == OP_CONVT) {
             ConvParams p{};
             p.Cout = o.out.C; p.M = B * e.tensors[o.in.t].H * e.tensors[o.in.t].W; p.Cin = o.in.C; p.ks = 1;
-            p.Kpad = (o.in.C + 31) / 32 * 32;
+            p.Kpad = (o.in.C + 31) / 32 * 32; p.cfg = o.cfg;
             o.kernel = conv_kernel_name(p, e.dtype);
         } else o.kernel = kn[o.kind];
     }
@@ -400,7 +402,7 @@ static ConvParams conv_params(const yp_engine& e, const Op& o) {
     p.M = e.pB * to.H * to.W; p.ks = o.k; p.stride = o.s; p.pad = o.k / 2; p.act = o.act;
     p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
     p.up = 1; p.oy = 0; p.ox = 0;
-    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes;
+    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.cfg = o.cfg;
     return p;
 }
 
@@ -430,7 +432,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
                     p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = ti.H; p.Wo = ti.W; p.Cout = o.out.C;
                     p.M = B * ti.H * ti.W; p.ks = 1; p.stride = 1; p.pad = 0; p.act = o.act; p.out_f32 = 0;
                     p.up = 2; p.oy = dy; p.ox = dx;
-                    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes;
+                    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.cfg = o.cfg;
                     hipError_t err = launch_conv(p, e.dtype, st);
                     if (err != hipSuccess) return err;
                 }
@@ -483,6 +485,49 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
         }
     }
     return hipErrorInvalidValue;
+}
+
+// Plan-time autotuner: for every dense conv that the LDS-DMA kernel supports, time each valid tile configuration on
+// the real tensors (weights are loaded, activations hold whatever the arena holds - timing does not depend on values
+// up to DVFS) and keep the fastest. Runs once per (B,H,W) plan, outside any graph capture.
+static int autotune(yp_engine& e) {
+    if (e.dtype != DT_BF16) return YP_OK;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0));
+    HIPCHK(hipEventCreate(&e1));
+    RunArgs none{nullptr, nullptr, nullptr, nullptr};
+    for (Op& o : e.ops) {
+        if (o.kind != OP_CONV && o.kind != OP_CONVT) continue;
+        ConvParams p{};
+        if (o.kind == OP_CONV) p = conv_params(e, o);
+        else { p.Cin = o.in.C; p.Cout = o.out.C; p.ks = 1; p.Kpad = e.weights[o.widx].Kpad; p.M = e.pB * e.tensors[o.in.t].H * e.tensors[o.in.t].W;
+               p.x_bytes = e.tensors[o.in.t].bytes; p.w_bytes = e.weights[o.widx].mat_bytes; }
+        if (!conv_dma_supported(p)) continue;
+        float best = 1e30f;
+        int bestc = -1;
+        for (int c = 0; c < conv_dma_num_cfgs(); ++c) {
+            if (!conv_dma_cfg_valid(p, c)) continue;
+            o.cfg = c;
+            float tmin = 1e30f;
+            for (int rep = 0; rep < 4; ++rep) {
+                HIPCHK(hipEventRecord(e0, nullptr));
+                hipError_t err = run_op(e, o, none, nullptr);
+                if (err != hipSuccess) return fail(YP_ERR_HIP, "autotune op %s cfg %d: %s", o.name.c_str(), c, hipGetErrorString(err));
+                HIPCHK(hipEventRecord(e1, nullptr));
+                HIPCHK(hipEventSynchronize(e1));
+                float ms = 0;
+                HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep > 0) tmin = std::min(tmin, ms);
+            }
+            if (tmin < best) { best = tmin; bestc = c; }
+        }
+        o.cfg = bestc;
+        if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
+        else { p.cfg = o.cfg; o.kernel = conv_kernel_name(p, e.dtype); }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return YP_OK;
 }
 
 static int run_all(yp_engine& e, const RunArgs& a, hipStream_t st) {
@@ -761,7 +806,15 @@ static int prepare(yp_engine* e, int B, int H, int W, const uint8_t* in, float* 
     if (!e->finalized) return fail(YP_ERR_STATE, "yp_finalize has not been called");
     int rc = make_plan(*e, B, H, W);
     if (rc != YP_OK) return rc;
-    return allocate_plan(*e);
+    const bool fresh = !e->allocated;
+    rc = allocate_plan(*e);
+    if (rc != YP_OK) return rc;
+    if (fresh && e->tune) {
+        HIPCHK(hipDeviceSynchronize());
+        rc = autotune(*e);
+        HIPCHK(hipDeviceSynchronize());
+    }
+    return rc;
 }
 
 int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
@@ -792,6 +845,17 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     HIPCHK(hipGraphLaunch(e->gexec, e->own_stream));
     HIPCHK(hipEventRecord(e->ev_out, e->own_stream));
     HIPCHK(hipStreamWaitEvent(st, e->ev_out, 0));
+    return YP_OK;
+}
+
+int yp_debug_force_conv_cfg(int cfg) {
+    conv_dma_force_cfg(cfg);
+    return conv_dma_num_cfgs();
+}
+
+int yp_set_autotune(yp_engine* e, int enable) {
+    if (!e) return fail(YP_ERR_ARG, "null engine");
+    e->tune = enable != 0;
     return YP_OK;
 }
 
