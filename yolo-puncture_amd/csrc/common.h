@@ -48,6 +48,7 @@ struct WeightDesc {
     std::vector<float> w, b;   // host fp32 copies until finalize
     // device, packed
     void* d_w = nullptr;       // layout depends on the consumer kernel
+    void* d_w2 = nullptr;      // stem only: bf16 [C0][32] GEMM layout for the MFMA stem
     float* d_b = nullptr;
     int Kpad = 0;
     size_t mat_bytes = 0;      // bytes of one packed GEMM matrix
@@ -99,6 +100,7 @@ struct DwParams {
 struct StemParams {
     const uint8_t* x; int H, W;       // [B,H,W,3] BGR
     const float* w;                   // [3][3][3(bgr)][C0]
+    const void* wpk;                  // bf16 [C0][32], k = (ky,kx,c_bgr), zero padded (MFMA stem); may be null
     const float* bias;
     void* y; int y_stride, y_coff; int Ho, Wo, C0; int B;
     int act;
@@ -128,6 +130,7 @@ struct HeadParams {
     int hw[3][2]; int nlev;
     int B, nc, max_det, A;
     float* det; int32_t* idx; float* coeff;   // user outputs
+    void* scratch;                            // device scratch, head_scratch_bytes(B, A)
 };
 
 // launches (implemented in the .hip files); dtype selects the template instance
@@ -145,6 +148,7 @@ hipError_t launch_pool5(const PoolParams& p, int dtype, hipStream_t st);
 hipError_t launch_upsample(const UpParams& p, int dtype, hipStream_t st);
 hipError_t launch_attention(const AttnParams& p, int dtype, hipStream_t st);
 hipError_t launch_head(const HeadParams& p, hipStream_t st);
+size_t head_scratch_bytes(int B, int A);
 
 struct MaskParams {
     const void* proto; int Hp, Wp;        // [Hp,Wp,32] engine dtype (one image)

@@ -46,6 +46,8 @@ struct yp_engine {
     size_t arena_bytes = 0;
     int proto_t = -1;
     void* mask_ws = nullptr;
+    void* head_ws = nullptr;
+    size_t head_ws_bytes = 0;
     size_t mask_ws_bytes = 0;
     // hipGraph replay
     bool use_graph = false;
@@ -319,7 +321,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     if (e.planned && e.pB == B && e.pH == H && e.pW == W) return YP_OK;
     size_t A = 0;
     for (int l = 0; l < 3; ++l) A += (size_t)(H / (8 << l)) * (W / (8 << l));
-    if (A > 16384) return fail(YP_ERR_ARG, "input %dx%d has %zu anchors; the LDS top-k supports at most 16384", H, W, A);
+    if (A > 12288) return fail(YP_ERR_ARG, "input %dx%d has %zu anchors; the LDS top-k supports at most 12288", H, W, A);
     for (auto& t : e.tensors) {
         t.H = H / t.sdiv; t.W = W / t.sdiv;
         t.bytes = (size_t)B * t.H * t.W * t.C * tensor_elem_bytes(e, t);
@@ -352,7 +354,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     }
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
     for (auto& o : e.ops) o.cfg = -1;
-    static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_topk_kernel", ""};
+    static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", ""};
     for (auto& o : e.ops) {
         if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
         else if (o.kind == OP_CONVT) {
@@ -380,6 +382,17 @@ static int allocate_plan(yp_engine& e) {
     for (auto& t : e.tensors) {
         t.ptr = (char*)e.arena + off;
         off += (t.bytes + 255) & ~(size_t)255;
+    }
+    {
+        size_t A = 0;
+        for (int l = 0; l < 3; ++l) A += (size_t)(e.pH / (8 << l)) * (e.pW / (8 << l));
+        const size_t need = head_scratch_bytes(e.pB, (int)A);
+        if (need > e.head_ws_bytes) {
+            if (e.head_ws) HIPCHK(hipFree(e.head_ws));
+            e.head_ws = nullptr;
+            HIPCHK(hipMalloc(&e.head_ws, need));
+            e.head_ws_bytes = need;
+        }
     }
     if (e.gexec) { (void)hipGraphExecDestroy(e.gexec); e.gexec = nullptr; }
     e.allocated = true;
@@ -414,7 +427,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             const WeightDesc& w = e.weights[o.widx];
             const TensorDesc& to = T(o.out);
             StemParams p{};
-            p.x = a.in; p.H = e.pH; p.W = e.pW; p.w = (const float*)w.d_w; p.bias = w.d_b;
+            p.x = a.in; p.H = e.pH; p.W = e.pW; p.w = (const float*)w.d_w; p.wpk = w.d_w2; p.bias = w.d_b;
             p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = to.H; p.Wo = to.W; p.C0 = o.out.C; p.B = B; p.act = o.act;
             return launch_stem(p, e.dtype, st);
         }
@@ -480,7 +493,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
                 p.hw[l][0] = tb.H; p.hw[l][1] = tb.W; p.A += tb.H * tb.W;
             }
             p.B = B; p.nc = e.desc.nc; p.max_det = e.desc.max_det;
-            p.det = a.det; p.idx = a.idx; p.coeff = (o.cf[0].t >= 0) ? a.coeff : nullptr;
+            p.det = a.det; p.idx = a.idx; p.coeff = (o.cf[0].t >= 0) ? a.coeff : nullptr; p.scratch = e.head_ws;
             return launch_head(p, st);
         }
     }
@@ -562,6 +575,13 @@ static int upload_weight(yp_engine& e, WeightDesc& w) {
                     }
         HIPCHK(hipMalloc(&w.d_w, f.size() * 4));
         HIPCHK(hipMemcpy(w.d_w, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+        if (e.dtype == DT_BF16) {   // GEMM layout for the MFMA stem: [co][k=(ky,kx,c_bgr)] bf16, K padded 27 -> 32
+            std::vector<uint16_t> g((size_t)w.cout * 32, 0);
+            for (int co = 0; co < w.cout; ++co)
+                for (int k = 0; k < 27; ++k) g[(size_t)co * 32 + k] = f2bf(f[(size_t)k * w.cout + co]);
+            HIPCHK(hipMalloc(&w.d_w2, g.size() * 2));
+            HIPCHK(hipMemcpy(w.d_w2, g.data(), g.size() * 2, hipMemcpyHostToDevice));
+        }
     } else if (w.groups > 1) {
         // depthwise: [k*k][C]
         const int C = w.cout, kk = w.k * w.k;
@@ -641,9 +661,10 @@ int yp_create(const yp_model_desc* desc, int device, yp_engine** out) {
 int yp_destroy(yp_engine* e) {
     if (!e) return YP_OK;
     if (e->finalized || e->arena) (void)hipSetDevice(e->device);
-    for (auto& w : e->weights) { if (w.d_w) (void)hipFree(w.d_w); if (w.d_b) (void)hipFree(w.d_b); }
+    for (auto& w : e->weights) { if (w.d_w) (void)hipFree(w.d_w); if (w.d_w2) (void)hipFree(w.d_w2); if (w.d_b) (void)hipFree(w.d_b); }
     if (e->arena) (void)hipFree(e->arena);
     if (e->mask_ws) (void)hipFree(e->mask_ws);
+    if (e->head_ws) (void)hipFree(e->head_ws);
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);

@@ -1,105 +1,191 @@
-// v10Detect one-to-one head epilogue + NMS-free post-process, one workgroup per image, all in LDS:
+// v10Detect one-to-one head epilogue + NMS-free post-process:
 //   sigmoid -> per-anchor class max -> top-k anchors -> top-k of (k x nc) -> DFL decode of the winners only.
 // Replaces Detect._inference (DFL, dist2bbox, make_anchors) + v10postprocess inside `.predict`
 // (reference yolo_seg/app.py:91); spec SURVEY.md A.4 / A.6 [U]. The [B,8400,4+nc] decoded tensor of the
 // reference is never materialised. Ordering rule: score descending, ties by flat index ascending
-// (stage 1: anchor index; stage 2: stage-1 rank * nc + class) - encoded in 64-bit keys so that one descending
-// sort implements it exactly.
+// (stage 1: anchor index; stage 2: stage-1 rank * nc + class) - encoded in unique 64-bit keys
+//   key = float_bits(score) << 32 | (0xFFFFFFFF - flat_index)
+// so "top-k by key" is exactly that rule. Two kernels:
+//   anchor_max_kernel  (whole chip)   : coalesced pass over the class logits, one key per anchor
+//   head_select_kernel (1 WG / image) : exact k-th-key radix select in LDS (8 x 8-bit passes over LDS histograms),
+//                                       compaction, 512-key bitonic sort; stage 2 prefilters the k*nc candidates
+//                                       with the stage-1 threshold and runs the same select in bounded rounds.
 #include "common.h"
 
 namespace yp {
 
-constexpr int HT = 1024;        // threads
-constexpr int NKEYS = 16384;    // LDS key capacity (128 KiB)
-constexpr int MAXK = 1024;      // max top-k supported
+constexpr int HT = 1024;         // threads of the select kernel
+constexpr int CAP = 12288;       // LDS key capacity of the select kernel (96 KiB)
+constexpr int MAXK = 512;        // max top-k supported (sorted with a 512-key bitonic network)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ unsigned long long make_key(float score, unsigned flat) {
+    return ((unsigned long long)__float_as_uint(score) << 32) | (unsigned long long)(0xFFFFFFFFu - flat);
+}
 
-// descending bitonic sort of n (power of two) 64-bit keys in LDS by all HT threads
-__device__ void bitonic_desc(unsigned long long* keys, int n) {
-    for (int k2 = 2; k2 <= n; k2 <<= 1) {
+struct Locate {
+    int A0, A1, A2;
+    __device__ __forceinline__ void operator()(int a, int& l, int& loc, int& HWl) const {
+        if (a < A0) { l = 0; loc = a; HWl = A0; }
+        else if (a < A0 + A1) { l = 1; loc = a - A0; HWl = A1; }
+        else { l = 2; loc = a - A0 - A1; HWl = A2; }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------------------
+// kernel 1: m[a] = sigmoid(max_c logit[a][c]); 16 lanes per anchor, coalesced 64-B reads
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void anchor_max_kernel(const HeadParams p, unsigned* __restrict__ mkey) {
+    const Locate locate{p.hw[0][0] * p.hw[0][1], p.hw[1][0] * p.hw[1][1], p.hw[2][0] * p.hw[2][1]};
+    const int sub = threadIdx.x & 15;
+    const long item = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;   // (image, anchor)
+    const long total = (long)p.B * p.A;
+    float mx = -INFINITY;
+    if (item < total) {
+        const int b = (int)(item / p.A), a = (int)(item - (long)b * p.A);
+        int l, loc, HWl;
+        locate(a, l, loc, HWl);
+        const float* cp = p.cls[l] + ((size_t)b * HWl + loc) * p.nc;
+        for (int c = sub; c < p.nc; c += 16) mx = fmaxf(mx, cp[c]);
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 16));
+    if (sub == 0 && item < total) mkey[item] = __float_as_uint(sigmoidf_(mx));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS helpers of kernel 2 (all HT threads participate)
+// ---------------------------------------------------------------------------------------------------------------
+struct SelectShared {
+    unsigned hist[256];
+    unsigned long long prefix;
+    unsigned want;
+    unsigned count;
+};
+
+// keys[0..n) -> the k largest keys, sorted descending, in out[0..k) (out may alias nothing in keys). n >= k.
+__device__ void select_topk_sorted(const unsigned long long* keys, int n, int k, unsigned long long* out512, SelectShared& S) {
+    const int tid = threadIdx.x;
+    if (tid == 0) { S.prefix = 0ull; S.want = (unsigned)k; }
+    __syncthreads();
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        if (tid < 256) S.hist[tid] = 0;
+        __syncthreads();
+        const unsigned long long pre = S.prefix;
+        for (int i = tid; i < n; i += HT) {
+            const unsigned long long key = keys[i];
+            if (pass == 0 || (key >> (shift + 8)) == pre) atomicAdd(&S.hist[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {   // one wave: find the bin holding the want-th largest key among the keys that match the prefix
+            // lane owns bins 4*lane .. 4*lane+3 ; suffix sums from the top
+            unsigned c0 = S.hist[4 * tid], c1 = S.hist[4 * tid + 1], c2 = S.hist[4 * tid + 2], c3 = S.hist[4 * tid + 3];
+            unsigned mine = c0 + c1 + c2 + c3;
+            unsigned above = 0;   // keys in bins of higher lanes
+            unsigned run = mine;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_down(run, o, 64);
+                if (tid + o < 64) run += t;
+            }
+            above = run - mine;   // sum over lanes > tid
+            const unsigned want = S.want;
+            // the target bin is in the unique lane with above < want <= above + mine
+            if (above < want && want <= above + mine) {
+                unsigned acc = above;
+                int bin;
+                if (want <= acc + c3) bin = 3;
+                else { acc += c3; if (want <= acc + c2) bin = 2; else { acc += c2; if (want <= acc + c1) bin = 1; else { acc += c1; bin = 0; } } }
+                S.prefix = (pre << 8) | (unsigned long long)(4 * tid + bin);
+                S.want = want - acc;
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned long long kth = S.prefix;   // exact k-th largest key (keys are unique)
+    if (tid == 0) S.count = 0;
+    for (int i = tid; i < 512; i += HT) out512[i] = 0ull;
+    __syncthreads();
+    for (int i = tid; i < n; i += HT) {
+        const unsigned long long key = keys[i];
+        if (key >= kth) out512[atomicAdd(&S.count, 1u)] = key;   // exactly k of them
+    }
+    __syncthreads();
+    // bitonic sort 512 keys descending (256 compare-exchanges per stage)
+    for (int k2 = 2; k2 <= 512; k2 <<= 1) {
         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int t = threadIdx.x; t < (n >> 1); t += HT) {
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+            if (tid < 256) {
+                const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
                 const int ixj = i + j;
-                const unsigned long long a = keys[i], b = keys[ixj];
+                const unsigned long long a = out512[i], b = out512[ixj];
                 const bool desc = (i & k2) == 0;
-                if ((a < b) == desc) { keys[i] = b; keys[ixj] = a; }
+                if ((a < b) == desc) { out512[i] = b; out512[ixj] = a; }
             }
             __syncthreads();
         }
     }
 }
 
-__device__ __forceinline__ int next_pow2(int v) {
-    int n = 2;
-    while (n < v) n <<= 1;
-    return n;
-}
-
-__global__ __launch_bounds__(HT) void head_topk_kernel(const HeadParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];   // [NKEYS]
-    int* sel = (int*)(keys + NKEYS);                                            // [MAXK] selected anchors (stage-1 order)
+__global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, const unsigned* __restrict__ mkey) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];
+    unsigned long long* keys = lds;                 // [CAP]
+    unsigned long long* best = lds + CAP;           // [512] sorted result of the last select
+    unsigned long long* carry = best + 512;         // [512] running best-k between stage-2 rounds
+    int* sel = (int*)(carry + 512);                 // [MAXK] stage-1 winners (anchor ids, rank order)
+    __shared__ SelectShared S;
+    __shared__ unsigned nfill;
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int A = p.A;
-    const int k = min(p.max_det, A);
-    const int A0 = p.hw[0][0] * p.hw[0][1];
-    const int A1 = (p.nlev > 1) ? p.hw[1][0] * p.hw[1][1] : 0;
+    const int A = p.A, k = min(p.max_det, A);
+    const Locate locate{p.hw[0][0] * p.hw[0][1], p.hw[1][0] * p.hw[1][1], p.hw[2][0] * p.hw[2][1]};
 
-    auto locate = [&](int a, int& l, int& loc, int& HWl) {
-        if (a < A0) { l = 0; loc = a; HWl = A0; }
-        else if (a < A0 + A1) { l = 1; loc = a - A0; HWl = A1; }
-        else { l = 2; loc = a - A0 - A1; HWl = p.hw[2][0] * p.hw[2][1]; }
-    };
-
-    // ---- stage 1: m[a] = max_c sigmoid(cls[a][c]) = sigmoid(max_c logit) -------------------------------
-    const int n1 = next_pow2(A);
-    for (int a = tid; a < n1; a += HT) {
-        unsigned long long key = 0ull;
-        if (a < A) {
-            int l, loc, HWl;
-            locate(a, l, loc, HWl);
-            const float* cp = p.cls[l] + ((size_t)b * HWl + loc) * p.nc;
-            float mx = cp[0];
-            for (int c = 1; c < p.nc; ++c) mx = fmaxf(mx, cp[c]);
-            const float s = sigmoidf_(mx);
-            key = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
-        }
-        keys[a] = key;
-    }
+    // ---- stage 1: top-k anchors by (max score desc, anchor asc) ---------------------------------------------------------
+    for (int a = tid; a < A; a += HT) keys[a] = ((unsigned long long)mkey[(size_t)b * A + a] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
     __syncthreads();
-    bitonic_desc(keys, n1);
-    for (int r = tid; r < k; r += HT) sel[r] = (int)(0xFFFFFFFFu - (unsigned)(keys[r] & 0xFFFFFFFFull));
+    select_topk_sorted(keys, A, k, best, S);
+    for (int r = tid; r < k; r += HT) sel[r] = (int)(0xFFFFFFFFu - (unsigned)(best[r] & 0xFFFFFFFFull));
+    const unsigned thr_bits = (unsigned)(best[k - 1] >> 32);   // every selected anchor has a class with score >= this
     __syncthreads();
 
-    // ---- stage 2: top-k of the k*nc (rank, class) candidates, in rounds that fit the LDS key buffer --------
+    // ---- stage 2: top-k of the k*nc (rank, class) candidates. A candidate below the stage-1 threshold can never be
+    //      in the result (>= k candidates reach it), so only survivors enter LDS; rounds bound the LDS use exactly. ----
     const int total = k * p.nc;
-    for (int i = tid; i < k; i += HT) keys[i] = 0ull;   // running best-k (0 = empty, sorts last)
-    __syncthreads();
+    int have = 0;                       // keys carried from earlier rounds (sorted, in carry[0..have))
     for (int done = 0; done < total;) {
-        const int take = min(total - done, NKEYS - k);
-        const int n2 = next_pow2(k + take);
-        for (int i = tid; i < n2 - k; i += HT) {
-            unsigned long long key = 0ull;
-            if (i < take) {
-                const int f = done + i;
+        if (tid == 0) nfill = (unsigned)have;
+        for (int i = tid; i < have; i += HT) keys[i] = carry[i];
+        __syncthreads();
+        // consume candidates until the buffer could overflow: each pass takes HT*? candidates; stop when nfill + chunk > CAP
+        int f0 = done;
+        while (f0 < total) {
+            const int chunk = min(total - f0, CAP - (int)nfill);
+            if (chunk <= 0) break;
+            const int take = min(chunk, total - f0);
+            for (int i = tid; i < take; i += HT) {
+                const int f = f0 + i;
                 const int r = f / p.nc, c = f - r * p.nc;
                 int l, loc, HWl;
                 locate(sel[r], l, loc, HWl);
                 const float s = sigmoidf_(p.cls[l][((size_t)b * HWl + loc) * p.nc + c]);
-                key = ((unsigned long long)__float_as_uint(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)f);
+                if (__float_as_uint(s) >= thr_bits) keys[atomicAdd(&nfill, 1u)] = make_key(s, (unsigned)f);
             }
-            keys[k + i] = key;
+            __syncthreads();
+            f0 += take;
+            if ((int)nfill + 1 >= CAP) break;
         }
+        done = f0;
+        const int n = (int)nfill;
+        const int kk = min(k, n);
+        select_topk_sorted(keys, n, kk, best, S);
+        for (int i = tid; i < kk; i += HT) carry[i] = best[i];
+        have = kk;
         __syncthreads();
-        bitonic_desc(keys, n2);
-        done += take;
     }
 
-    // ---- winners: DFL decode (softmax expectation over 16 bins per side), dist2bbox (xyxy) * stride ----------
+    // ---- winners: DFL decode (softmax expectation over 16 bins per side), dist2bbox (xyxy) * stride ----------------------
     for (int r = tid; r < p.max_det; r += HT) {
         float* d = p.det + ((size_t)b * p.max_det + r) * 6;
-        if (r >= k) {
+        if (r >= have) {
 #pragma unroll
             for (int j = 0; j < 6; ++j) d[j] = 0.f;
             if (p.idx) p.idx[(size_t)b * p.max_det + r] = -1;
@@ -107,7 +193,7 @@ __global__ __launch_bounds__(HT) void head_topk_kernel(const HeadParams p) {
                 for (int j = 0; j < 32; ++j) p.coeff[((size_t)b * p.max_det + r) * 32 + j] = 0.f;
             continue;
         }
-        const unsigned long long key = keys[r];
+        const unsigned long long key = carry[r];
         const float score = __uint_as_float((unsigned)(key >> 32));
         const int f = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
         const int row = f / p.nc, cls = f - row * p.nc;
@@ -147,16 +233,21 @@ __global__ __launch_bounds__(HT) void head_topk_kernel(const HeadParams p) {
     }
 }
 
+size_t head_scratch_bytes(int B, int A) { return (size_t)B * A * sizeof(unsigned); }
+
 hipError_t launch_head(const HeadParams& p, hipStream_t st) {
-    if (p.A > NKEYS || p.max_det > MAXK || p.max_det * 2 > NKEYS) return hipErrorInvalidValue;
-    const size_t sh = (size_t)NKEYS * 8 + MAXK * 4;
+    if (p.A > CAP || p.max_det > MAXK || p.scratch == nullptr) return hipErrorInvalidValue;
+    const size_t sh = (size_t)(CAP + 1024) * 8 + MAXK * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)head_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipError_t e = hipFuncSetAttribute((const void*)head_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(head_topk_kernel, dim3(p.B), dim3(HT), sh, st, p);
+    unsigned* mkey = (unsigned*)p.scratch;
+    const long items = (long)p.B * p.A * 16;
+    hipLaunchKernelGGL(anchor_max_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, mkey);
+    hipLaunchKernelGGL(head_select_kernel, dim3(p.B), dim3(HT), sh, st, p, mkey);
     return hipGetLastError();
 }
 

@@ -94,9 +94,102 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemParams p) {
     o.store((T*)p.y + (size_t)pix * p.y_stride + p.y_coff + g * 8);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// bf16 stem on the matrix cores: one workgroup = 256 output pixels. Each thread builds the im2col row of its pixel
+// (27 taps of uint8 -> x/255 -> bf16, zero-padded to K=32) straight into LDS, then 4 waves run
+// D[cout][pixel] = W[cout][32] * X[pixel][32] with MFMA 16x16x32 and store 4 consecutive couts per lane.
+// ---------------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+__device__ __forceinline__ int swz32(int row) { return ((row >> 2) & 1) << 1; }
+
+template <int FN>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, const __bf16* __restrict__ wpk) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[256 * 64 + FN * 16 * 64];
+    unsigned char* Xs = lds;
+    unsigned char* Ws = lds + 256 * 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long M = (long)p.B * p.Ho * p.Wo;
+    const long m = (long)blockIdx.x * 256 + tid;
+    // ---- im2col row of this thread's pixel ---------------------------------------------------------------
+    {
+        __attribute__((aligned(16))) __bf16 row[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) row[i] = (__bf16)0.f;
+        if (m < M) {
+            const int wo = (int)(m % p.Wo);
+            const int ho = (int)((m / p.Wo) % p.Ho);
+            const int b = (int)(m / ((long)p.Wo * p.Ho));
+            const uint8_t* xb = p.x + (size_t)b * p.H * p.W * 3;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int hi = ho * 2 - 1 + ky;
+                const bool rok = (unsigned)hi < (unsigned)p.H;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int wi = wo * 2 - 1 + kx;
+                    const bool ok = rok && ((unsigned)wi < (unsigned)p.W);
+                    const uint8_t* px = xb + ((size_t)(ok ? hi : 0) * p.W + (ok ? wi : 0)) * 3;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        const float v = ok ? ((float)px[c] / 255.0f) : 0.f;
+                        row[(ky * 3 + kx) * 3 + c] = (__bf16)v;
+                    }
+                }
+            }
+        }
+        const uint4* r4 = (const uint4*)row;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *(uint4*)(Xs + tid * 64 + ((c ^ swz32(tid)) * 16)) = r4[c];
+    }
+    for (int i = tid; i < FN * 16 * 4; i += 256) {
+        const int r = i >> 2, c = i & 3;
+        *(uint4*)(Ws + r * 64 + ((c ^ swz32(r)) * 16)) = *(const uint4*)(wpk + r * 32 + c * 8);
+    }
+    __syncthreads();
+    const int fr = lane & 15, fc = lane >> 4;
+    bf16x8_t wf[FN], xf[4];
+#pragma unroll
+    for (int a = 0; a < FN; ++a) { const int r = a * 16 + fr; wf[a] = *(const bf16x8_t*)(Ws + r * 64 + ((fc ^ swz32(r)) * 16)); }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { const int r = wave * 64 + b * 16 + fr; xf[b] = *(const bf16x8_t*)(Xs + r * 64 + ((fc ^ swz32(r)) * 16)); }
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        const int co = a * 16 + fc * 4;
+        const float4 bs = *(const float4*)(p.bias + co);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc, 0, 0, 0);
+            const long mm = (long)blockIdx.x * 256 + wave * 64 + b * 16 + fr;
+            if (mm >= M) continue;
+            float v[4] = {acc[0] + bs.x, acc[1] + bs.y, acc[2] + bs.z, acc[3] + bs.w};
+            if (p.act == ACT_SILU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+            }
+            __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+            *(uint2*)((__bf16*)p.y + (size_t)mm * p.y_stride + p.y_coff + co) = *(const uint2*)o;
+        }
+    }
+}
+
 hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st) {
     const long total = (long)p.B * p.Ho * p.Wo * (p.C0 / 8);
     const int blk = 256;
+    if (dtype == DT_BF16 && p.wpk && (p.C0 % 16) == 0 && p.C0 <= 80 && (p.y_stride & 3) == 0 && (p.y_coff & 3) == 0) {
+        const long M = (long)p.B * p.Ho * p.Wo;
+        const unsigned grid = (unsigned)((M + 255) / 256);
+        const __bf16* w = (const __bf16*)p.wpk;
+        switch (p.C0 / 16) {
+            case 1: hipLaunchKernelGGL(stem_mfma_kernel<1>, dim3(grid), dim3(256), 0, st, p, w); break;
+            case 2: hipLaunchKernelGGL(stem_mfma_kernel<2>, dim3(grid), dim3(256), 0, st, p, w); break;
+            case 3: hipLaunchKernelGGL(stem_mfma_kernel<3>, dim3(grid), dim3(256), 0, st, p, w); break;
+            case 4: hipLaunchKernelGGL(stem_mfma_kernel<4>, dim3(grid), dim3(256), 0, st, p, w); break;
+            default: hipLaunchKernelGGL(stem_mfma_kernel<5>, dim3(grid), dim3(256), 0, st, p, w); break;
+        }
+        return hipGetLastError();
+    }
     const unsigned grid = (unsigned)((total + blk - 1) / blk);
     const size_t sh = (size_t)(28 * p.C0) * sizeof(float);
     if (dtype == DT_BF16) hipLaunchKernelGGL(stem_kernel<__bf16>, dim3(grid), dim3(blk), sh, st, p);
@@ -159,13 +252,108 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
     o.store((T*)p.y + (size_t)pix * p.y_stride + p.y_coff + c);
 }
 
-hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st) {
-    const long total = (long)p.B * p.Ho * p.Wo * (p.C / 8);
-    const int blk = 256;
-    const unsigned grid = (unsigned)((total + blk - 1) / blk);
-    if (dtype == DT_BF16) hipLaunchKernelGGL(dwconv_kernel<__bf16>, dim3(grid), dim3(blk), 0, st, p);
-    else hipLaunchKernelGGL(dwconv_kernel<float>, dim3(grid), dim3(blk), 0, st, p);
+// NOUT consecutive output pixels of one row per thread: the input columns are loaded once per kernel row and reused
+// by every output they cover, the weights of a kernel row are loaded once per thread.
+template <typename T, int KS, int S, int NOUT>
+__global__ __launch_bounds__(256) void dwconv_row_kernel(const DwParams p) {
+    constexpr int NCOL = (NOUT - 1) * S + KS;
+    const int groups = p.C >> 3;
+    const int wq = (p.Wo + NOUT - 1) / NOUT;
+    const long total = (long)p.B * p.Ho * wq * groups;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= total) return;
+    const int g = (int)(gid % groups);
+    long t = gid / groups;
+    const int wo0 = (int)(t % wq) * NOUT;
+    t /= wq;
+    const int ho = (int)(t % p.Ho);
+    const int b = (int)(t / p.Ho);
+    const int c = g * 8;
+    const int cin = p.gs ? (p.x_coff + (c / p.gs) * p.gstride + (c % p.gs)) : (p.x_coff + c);
+    float acc[NOUT][8];
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[o][j] = p.bias[c + j];
+    const T* xb = (const T*)p.x + (size_t)b * p.H * p.W * p.x_stride + cin;
+    const T* wb = (const T*)p.w + c;
+    const int wi0 = wo0 * S - p.pad;
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+        const int hi = ho * S - p.pad + ky;
+        if ((unsigned)hi >= (unsigned)p.H) continue;
+        float wf[KS][8];
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) {
+            Vec8<T> wv;
+            wv.load(wb + (size_t)(ky * KS + kx) * p.C);
+            wv.unpack(wf[kx]);
+        }
+#pragma unroll
+        for (int col = 0; col < NCOL; ++col) {
+            const int wi = wi0 + col;
+            float xf[8];
+            if ((unsigned)wi < (unsigned)p.W) {
+                Vec8<T> xv;
+                xv.load(xb + ((size_t)hi * p.W + wi) * p.x_stride);
+                xv.unpack(xf);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[j] = 0.f;
+            }
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) {
+                const int kx = col - o * S;
+                if (kx >= 0 && kx < KS) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[o][j] = fmaf(xf[j], wf[kx][j], acc[o][j]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+        const int wo = wo0 + o;
+        if (wo >= p.Wo) break;
+        const size_t pix = ((size_t)b * p.Ho + ho) * p.Wo + wo;
+        if (p.act == ACT_SILU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[o][j] = silu_f(acc[o][j]);
+        }
+        if (p.res) {
+            Vec8<T> rv;
+            rv.load((const T*)p.res + pix * p.res_stride + p.res_coff + c);
+            float rf[8];
+            rv.unpack(rf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[o][j] += rf[j];
+        }
+        Vec8<T> ov;
+        ov.pack(acc[o]);
+        ov.store((T*)p.y + pix * p.y_stride + p.y_coff + c);
+    }
+}
+
+template <typename T, int KS, int S, int NOUT>
+static void launch_dw_row(const DwParams& p, hipStream_t st) {
+    const long total = (long)p.B * p.Ho * ((p.Wo + NOUT - 1) / NOUT) * (p.C / 8);
+    hipLaunchKernelGGL((dwconv_row_kernel<T, KS, S, NOUT>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+}
+
+template <typename T>
+static hipError_t launch_dwconv_t(const DwParams& p, hipStream_t st) {
+    if (p.ks == 3 && p.stride == 1) launch_dw_row<T, 3, 1, 4>(p, st);
+    else if (p.ks == 3 && p.stride == 2) launch_dw_row<T, 3, 2, 2>(p, st);
+    else if (p.ks == 7 && p.stride == 1) launch_dw_row<T, 7, 1, 2>(p, st);
+    else {
+        const long total = (long)p.B * p.Ho * p.Wo * (p.C / 8);
+        hipLaunchKernelGGL(dwconv_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
+    }
     return hipGetLastError();
+}
+
+hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st) {
+    return dtype == DT_BF16 ? launch_dwconv_t<__bf16>(p, st) : launch_dwconv_t<float>(p, st);
 }
 
 // ---------------------------------------------------------------------------------------------------------
