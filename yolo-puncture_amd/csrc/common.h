@@ -141,6 +141,12 @@ bool conv_dma_supported(const ConvParams& p);
 const char* conv_dma_kernel_name(const ConvParams& p);
 int conv_dma_num_cfgs();
 void conv_dma_force_cfg(int cfg);
+int conv_dma_forced_cfg();
+// halo-tiled 3x3 s1 kernel (conv_halo.hip); configuration ids are offset by 100 in ConvParams::cfg
+int conv_halo_num_cfgs();
+bool conv_halo_cfg_valid(const ConvParams& p, int c);
+const char* conv_halo_kernel_name(int c);
+hipError_t launch_conv_halo(const ConvParams& p, int c, hipStream_t st);
 bool conv_dma_cfg_valid(const ConvParams& p, int cfg);
 hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st);

@@ -534,6 +534,24 @@ static int autotune(yp_engine& e) {
             }
             if (tmin < best) { best = tmin; bestc = c; }
         }
+        if (o.kind == OP_CONV) {
+            for (int c = 0; c < conv_halo_num_cfgs(); ++c) {
+                if (!conv_halo_cfg_valid(p, c)) continue;
+                o.cfg = 100 + c;
+                float tmin = 1e30f;
+                for (int rep = 0; rep < 4; ++rep) {
+                    HIPCHK(hipEventRecord(e0, nullptr));
+                    hipError_t err = run_op(e, o, none, nullptr);
+                    if (err != hipSuccess) return fail(YP_ERR_HIP, "autotune op %s halo cfg %d: %s", o.name.c_str(), c, hipGetErrorString(err));
+                    HIPCHK(hipEventRecord(e1, nullptr));
+                    HIPCHK(hipEventSynchronize(e1));
+                    float ms = 0;
+                    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+                    if (rep > 0) tmin = std::min(tmin, ms);
+                }
+                if (tmin < best) { best = tmin; bestc = 100 + c; }
+            }
+        }
         o.cfg = bestc;
         if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
         else { p.cfg = o.cfg; o.kernel = conv_kernel_name(p, e.dtype); }
