@@ -83,7 +83,7 @@ struct ConvParams {
     int ks, stride, pad;
     int act, out_f32;
     int up, oy, ox;                             // output pixel (ho,wo) -> (ho*up+oy, wo*up+ox) in an (Ho*up,Wo*up) image
-    size_t x_bytes, w_bytes;                    // extents of the x tensor / packed weight matrix (buffer descriptors)
+    size_t x_bytes, w_bytes, y_bytes;           // extents of the x / packed-weight / y buffers (buffer descriptors)
     int cfg;                                    // conv_dma tile configuration (-1: heuristic)
 };
 
@@ -147,6 +147,11 @@ int conv_halo_num_cfgs();
 bool conv_halo_cfg_valid(const ConvParams& p, int c);
 const char* conv_halo_kernel_name(int c);
 hipError_t launch_conv_halo(const ConvParams& p, int c, hipStream_t st);
+// persistent weight-resident halo kernel (conv_halo_p.hip); ids offset by 200
+int conv_halo_p_num_cfgs();
+bool conv_halo_p_cfg_valid(const ConvParams& p, int c);
+const char* conv_halo_p_kernel_name(int c);
+hipError_t launch_conv_halo_p(const ConvParams& p, int c, hipStream_t st);
 bool conv_dma_cfg_valid(const ConvParams& p, int cfg);
 hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st);

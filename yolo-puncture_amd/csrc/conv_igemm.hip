@@ -239,19 +239,26 @@ static int conv_tile_choice(const ConvParams& p) {
     if ((p.Cout % 128) != 0 || p.M < 128 * 256) return 1;
     return 2;
 }
-// halo configuration selected for p (explicit p.cfg >= 100, or the test override), or -1
+// halo configuration selected for p (explicit p.cfg in [100,200) / [200,300), or the test override), or -1.
+// returns 100+c (conv_halo) or 200+c (conv_halo_p)
 static int halo_choice(const ConvParams& p, int dtype) {
     if (dtype != DT_BF16) return -1;
+    auto valid = [&](int c) {
+        if (c >= 200) return conv_halo_p_cfg_valid(p, c - 200);
+        if (c >= 100) return conv_halo_cfg_valid(p, c - 100);
+        return false;
+    };
     const int f = conv_dma_forced_cfg();
-    if (f >= 100 && conv_halo_cfg_valid(p, f - 100)) return f - 100;
+    if (f >= 100 && valid(f)) return f;
     if (f >= 0 && f < 100) return -1;
-    if (p.cfg >= 100 && conv_halo_cfg_valid(p, p.cfg - 100)) return p.cfg - 100;
+    if (p.cfg >= 100 && valid(p.cfg)) return p.cfg;
     return -1;
 }
 
 const char* conv_kernel_name(const ConvParams& p, int dtype) {
     const int h = halo_choice(p, dtype);
-    if (h >= 0) return conv_halo_kernel_name(h);
+    if (h >= 200) return conv_halo_p_kernel_name(h - 200);
+    if (h >= 100) return conv_halo_kernel_name(h - 100);
     if (dtype == DT_BF16 && conv_dma_supported(p)) return conv_dma_kernel_name(p);
     static const char* names[2][3] = {
         {"conv_igemm_kernel<bf16,128,32,4,1>", "conv_igemm_kernel<bf16,128,64,2,2>", "conv_igemm_kernel<bf16,128,128,2,2>"},
@@ -280,7 +287,8 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t st) {
 
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st) {
     const int h = halo_choice(p, dtype);
-    if (h >= 0) return launch_conv_halo(p, h, st);
+    if (h >= 200) return launch_conv_halo_p(p, h - 200, st);
+    if (h >= 100) return launch_conv_halo(p, h - 100, st);
     if (dtype == DT_BF16 && conv_dma_supported(p)) return launch_conv_dma(p, st);
     if (dtype == DT_BF16) return launch_conv_t<__bf16>(p, st);
     return launch_conv_t<float>(p, st);

@@ -415,7 +415,7 @@ static ConvParams conv_params(const yp_engine& e, const Op& o) {
     p.M = e.pB * to.H * to.W; p.ks = o.k; p.stride = o.s; p.pad = o.k / 2; p.act = o.act;
     p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
     p.up = 1; p.oy = 0; p.ox = 0;
-    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.cfg = o.cfg;
+    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.y_bytes = to.bytes; p.cfg = o.cfg;
     return p;
 }
 
@@ -445,7 +445,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
                     p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = ti.H; p.Wo = ti.W; p.Cout = o.out.C;
                     p.M = B * ti.H * ti.W; p.ks = 1; p.stride = 1; p.pad = 0; p.act = o.act; p.out_f32 = 0;
                     p.up = 2; p.oy = dy; p.ox = dx;
-                    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.cfg = o.cfg;
+                    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.y_bytes = to.bytes; p.cfg = o.cfg;
                     hipError_t err = launch_conv(p, e.dtype, st);
                     if (err != hipSuccess) return err;
                 }
@@ -535,21 +535,23 @@ static int autotune(yp_engine& e) {
             if (tmin < best) { best = tmin; bestc = c; }
         }
         if (o.kind == OP_CONV) {
-            for (int c = 0; c < conv_halo_num_cfgs(); ++c) {
-                if (!conv_halo_cfg_valid(p, c)) continue;
-                o.cfg = 100 + c;
+            std::vector<int> cands;
+            for (int c = 0; c < conv_halo_num_cfgs(); ++c) if (conv_halo_cfg_valid(p, c)) cands.push_back(100 + c);
+            for (int c = 0; c < conv_halo_p_num_cfgs(); ++c) if (conv_halo_p_cfg_valid(p, c)) cands.push_back(200 + c);
+            for (int cc : cands) {
+                o.cfg = cc;
                 float tmin = 1e30f;
                 for (int rep = 0; rep < 4; ++rep) {
                     HIPCHK(hipEventRecord(e0, nullptr));
                     hipError_t err = run_op(e, o, none, nullptr);
-                    if (err != hipSuccess) return fail(YP_ERR_HIP, "autotune op %s halo cfg %d: %s", o.name.c_str(), c, hipGetErrorString(err));
+                    if (err != hipSuccess) return fail(YP_ERR_HIP, "autotune op %s cfg %d: %s", o.name.c_str(), cc, hipGetErrorString(err));
                     HIPCHK(hipEventRecord(e1, nullptr));
                     HIPCHK(hipEventSynchronize(e1));
                     float ms = 0;
                     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
                     if (rep > 0) tmin = std::min(tmin, ms);
                 }
-                if (tmin < best) { best = tmin; bestc = 100 + c; }
+                if (tmin < best) { best = tmin; bestc = cc; }
             }
         }
         o.cfg = bestc;
