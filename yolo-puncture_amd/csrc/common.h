@@ -147,6 +147,11 @@ int conv_halo_num_cfgs();
 bool conv_halo_cfg_valid(const ConvParams& p, int c);
 const char* conv_halo_kernel_name(int c);
 hipError_t launch_conv_halo(const ConvParams& p, int c, hipStream_t st);
+// persistent im2col kernel (conv_dma_p.hip); ids offset by 300
+int conv_dma_p_num_cfgs();
+bool conv_dma_p_cfg_valid(const ConvParams& p, int c);
+const char* conv_dma_p_kernel_name(int c);
+hipError_t launch_conv_dma_p(const ConvParams& p, int c, hipStream_t st);
 // persistent weight-resident halo kernel (conv_halo_p.hip); ids offset by 200
 int conv_halo_p_num_cfgs();
 bool conv_halo_p_cfg_valid(const ConvParams& p, int c);

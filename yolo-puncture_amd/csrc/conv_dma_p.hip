@@ -1,0 +1,323 @@
+// Persistent form of conv_dma.hip (bf16 implicit-GEMM conv on MFMA with an LDS-DMA operand ring): a workgroup keeps its
+// output-channel block and walks pixel tiles j, j+G, j+2G, ...; the k-step ring runs straight across tile boundaries, so
+// the loads of the next tile are in flight while the current tile finishes and stores. PMC profiles (profiles/r01_*)
+// showed the one-tile-per-workgroup form spending most of a wave's life in its prologue / first-load latency / store tail.
+//
+// vmcnt accounting (see conv_halo_p.hip): per wave the queue holds LPW LDS-DMA loads per k-step and S = FM*FN epilogue
+// stores per tile, the stores issued unconditionally through a buffer descriptor (out-of-range offset when a lane has
+// nothing to store). Iteration g: wait(g) ; barrier ; issue(g+NS-1) ; compute(g) ; [stores if g ends a tile].
+// Ops younger than L(g) at wait(g): L(g+1..g+NS-2) plus the stores of every tile end among the previous NS-1 iterations
+// -> s_waitcnt vmcnt((NS-2)*LPW + k*S), k = 0..NS-1.
+#include "common.h"
+
+namespace yp {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ float silu_f2(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+template <int N> __device__ __forceinline__ void wait_vmp() {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | (7 << 4) | (0xF << 8) | (((N >> 4) & 3) << 14));
+}
+template <int BK> __device__ __forceinline__ int swz_p(int row) {
+    return BK == 32 ? (((row >> 2) & 1) << 1) : ((row >> 1) & 7);
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32>
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvParams p, const int mtiles, const int ntiles, const int G) {
+    constexpr int NW = WGM * WGN;
+    constexpr int CPR = BK / 8;
+    constexpr int RB = BK * 2;
+    constexpr int A_INSTR = BM * CPR / 64;
+    constexpr int W_INSTR = BN * CPR / 64;
+    constexpr int A_IPW = A_INSTR / NW;
+    constexpr int W_IPW = (W_INSTR + NW - 1) / NW;
+    constexpr int LPW = A_IPW + W_IPW;
+    constexpr int SB = (BM + BN) * RB;
+    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
+    constexpr int KSUB = BK / 32;
+    constexpr int S = FM * FN;
+    static_assert((NW == 4 || NW == 8) && A_INSTR % NW == 0 && A_IPW >= 1, "tile/wave layout");
+    static_assert((NS - 2) * LPW + (NS - 1) * S < 64, "vmcnt immediate");
+    constexpr unsigned OOB = 0x80000000u;
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WGM, wn = wave / WGM;
+    const int fr = lane & 15, fc = lane >> 4;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int nt = bid % ntiles, j0 = bid / ntiles;
+    const int n0 = nt * BN;
+    const int HoWo = p.Ho * p.Wo;
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
+
+    float bias[FN][4];
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        const int co = n0 + wn * WN + a * 16 + fc * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[a][r] = (co + r < p.Cout) ? p.bias[co + r] : 0.f;
+    }
+
+    // ---- issue side -----------------------------------------------------------------------------------------
+    unsigned aconst[A_IPW], amask[A_IPW];
+    auto set_tile = [&](int mt) {
+#pragma unroll
+        for (int j = 0; j < A_IPW; ++j) {
+            const int s = (wave * A_IPW + j) * 64 + lane;
+            const int row = s / CPR, pc = s - row * CPR;
+            const int c = pc ^ swz_p<BK>(row);
+            const int m = mt * BM + row;
+            unsigned mask = 0, base = 0;
+            if (mt < mtiles && m < p.M) {
+                if (p.ks == 1) {
+                    base = (unsigned)(m * p.x_stride + p.x_coff) * 2u;
+                    mask = 1u;
+                } else {
+                    const int b = m / HoWo, r = m - b * HoWo;
+                    const int ho = r / p.Wo, wo = r - ho * p.Wo;
+                    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+                    base = (unsigned)(((b * p.H + hi0) * p.W + wi0) * p.x_stride + p.x_coff) * 2u;
+                    for (int ky = 0; ky < p.ks; ++ky)
+                        for (int kx = 0; kx < p.ks; ++kx)
+                            if ((unsigned)(hi0 + ky) < (unsigned)p.H && (unsigned)(wi0 + kx) < (unsigned)p.W)
+                                mask |= 1u << (ky * p.ks + kx);
+                }
+            }
+            aconst[j] = base + (unsigned)c * 16u;
+            amask[j] = mask;
+        }
+    };
+    unsigned wconst[W_IPW];
+#pragma unroll
+    for (int j = 0; j < W_IPW; ++j) {
+        const int ii = wave * W_IPW + j;
+        const int s = ii * 64 + lane;
+        const int row = s / CPR, pc = s - row * CPR;
+        const int c = pc ^ swz_p<BK>(row);
+        wconst[j] = (ii < W_INSTR) ? (unsigned)(((n0 + row) * p.Kpad + c * 8) * 2) : OOB;
+    }
+    const int nk = p.Kpad / BK;
+    int it_tile = j0, it_kt = 0, it_slot = 0;
+    int is_tap = 0, is_ky = 0, is_kx = 0, is_kc = 0;
+    set_tile(it_tile);
+    auto issue_next = [&]() {
+        const unsigned tapoff = (unsigned)(((is_ky * p.W + is_kx) * p.x_stride + is_kc) * 2);
+        unsigned char* sbase = smem + it_slot * SB;
+#pragma unroll
+        for (int j = 0; j < A_IPW; ++j) {
+            const unsigned voff = ((amask[j] >> is_tap) & 1u) ? (aconst[j] + tapoff) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(sbase + (wave * A_IPW + j) * 1024), 16, voff, 0, 0, 0);
+        }
+        const bool live = it_tile < mtiles;
+#pragma unroll
+        for (int j = 0; j < W_IPW; ++j) {
+            const int ii = wave * W_IPW + j;
+            unsigned char* dst = (ii < W_INSTR) ? (sbase + BM * RB + ii * 1024) : (smem + NS * SB);
+            const unsigned voff = (wconst[j] == OOB || !live) ? OOB : (wconst[j] + (unsigned)(it_kt * BK) * 2u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)dst, 16, voff, 0, 0, 0);
+        }
+        it_slot = (it_slot + 1 == NS) ? 0 : it_slot + 1;
+        is_kc += BK;
+        if (is_kc >= p.Cin) {
+            is_kc = 0;
+            ++is_tap;
+            if (++is_kx == p.ks) { is_kx = 0; ++is_ky; }
+        }
+        if (++it_kt == nk) {
+            it_kt = 0; is_tap = 0; is_ky = 0; is_kx = 0; is_kc = 0;
+            it_tile += G;
+            set_tile(it_tile);
+        }
+    };
+
+    // fragment read offsets
+    int aoff[KSUB], woff[KSUB];
+#pragma unroll
+    for (int ss = 0; ss < KSUB; ++ss) {
+        const int ra = wm * WM + fr, rw = wn * WN + fr;
+        aoff[ss] = ra * RB + (((ss * 4 + fc) ^ swz_p<BK>(ra)) * 16);
+        woff[ss] = BM * RB + rw * RB + (((ss * 4 + fc) ^ swz_p<BK>(rw)) * 16);
+    }
+
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_next();
+
+    int rslot = 0;
+    unsigned epmask = 0;
+    for (int tile = j0; tile < mtiles; tile += G) {
+        f32x4 acc[FN][FM];
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nk; ++kt) {
+            {
+                const int k = __builtin_popcount(epmask & ((1u << (NS - 1)) - 1u));
+                if (k == 0) wait_vmp<(NS - 2) * LPW>();
+                else if (k == 1) wait_vmp<(NS - 2) * LPW + S>();
+                else if (k == 2) wait_vmp<(NS - 2) * LPW + 2 * S>();
+                else wait_vmp<(NS - 2) * LPW + (NS >= 4 ? 3 : 2) * S>();
+            }
+            __builtin_amdgcn_s_barrier();
+            issue_next();
+            epmask <<= 1;
+            const unsigned char* sb = smem + rslot * SB;
+#pragma unroll
+            for (int ss = 0; ss < KSUB; ++ss) {
+                bf16x8 wf[FN], xf[FM];
+#pragma unroll
+                for (int a = 0; a < FN; ++a) wf[a] = *(const bf16x8*)(sb + woff[ss] + a * 16 * RB);
+#pragma unroll
+                for (int b = 0; b < FM; ++b) xf[b] = *(const bf16x8*)(sb + aoff[ss] + b * 16 * RB);
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int b = 0; b < FM; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+            }
+            rslot = (rslot + 1 == NS) ? 0 : rslot + 1;
+        }
+
+        // ---- epilogue: exactly S buffer stores per wave ---------------------------------------------------------
+        {
+            const int m0 = tile * BM;
+            uint2 rres[FM][FN];
+            if (HAS_RES) {
+#pragma unroll
+                for (int b = 0; b < FM; ++b) {
+                    const int m = m0 + wm * WM + b * 16 + fr;
+#pragma unroll
+                    for (int a = 0; a < FN; ++a) {
+                        const int co = n0 + wn * WN + a * 16 + fc * 4;
+                        rres[b][a] = (m < p.M && co < p.Cout)
+                                         ? *(const uint2*)((const __bf16*)p.res + (size_t)m * p.res_stride + p.res_coff + co)
+                                         : make_uint2(0u, 0u);
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const int m = m0 + wm * WM + b * 16 + fr;
+#pragma unroll
+                for (int a = 0; a < FN; ++a) {
+                    const int co = n0 + wn * WN + a * 16 + fc * 4;
+                    const bool ok = (m < p.M) && (co < p.Cout);
+                    float v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float tt = acc[a][b][i] + bias[a][i];
+                        if (p.act == ACT_SILU) tt = silu_f2(tt);
+                        v[i] = tt;
+                    }
+                    if (HAS_RES) {
+                        const uint2 rr = rres[b][a];
+                        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                    }
+                    if (OUT_F32) {
+                        const unsigned off = ok ? ((unsigned)m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 4u : OOB;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(v[0], v[1], v[2], v[3])), yrs, off, 0, 0);
+                    } else {
+                        const unsigned off = ok ? ((unsigned)m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 2u : OOB;
+                        __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                        __builtin_amdgcn_raw_buffer_store_b64(*(const __attribute__((ext_vector_type(2))) unsigned*)o, yrs, off, 0, 0);
+                    }
+                }
+            }
+        }
+        epmask |= 1u;
+    }
+    wait_vmp<0>();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct DmaPCfg { int BM, BN, NW, BK, NS; const char* name; };
+static const DmaPCfg kP[] = {
+    {128, 32, 4, 32, 4, "conv_dma_p_kernel<128,32,4,1,32,4>"},     // 0
+    {128, 64, 4, 32, 4, "conv_dma_p_kernel<128,64,2,2,32,4>"},     // 1
+    {128, 128, 4, 32, 4, "conv_dma_p_kernel<128,128,2,2,32,4>"},   // 2
+    {64, 64, 4, 32, 4, "conv_dma_p_kernel<64,64,2,2,32,4>"},       // 3
+    {256, 64, 8, 32, 4, "conv_dma_p_kernel<256,64,4,2,32,4>"},     // 4
+    {256, 128, 8, 32, 4, "conv_dma_p_kernel<256,128,4,2,32,4>"},   // 5
+    {128, 128, 4, 64, 3, "conv_dma_p_kernel<128,128,2,2,64,3>"},   // 6
+    {128, 64, 4, 64, 3, "conv_dma_p_kernel<128,64,2,2,64,3>"},     // 7
+    {128, 256, 8, 32, 4, "conv_dma_p_kernel<128,256,2,4,32,4>"},   // 8
+    {64, 128, 4, 64, 3, "conv_dma_p_kernel<64,128,2,2,64,3>"},     // 9
+    {64, 64, 4, 64, 4, "conv_dma_p_kernel<64,64,2,2,64,4>"},       // 10
+    {128, 64, 8, 64, 4, "conv_dma_p_kernel<128,64,4,2,64,4>"},     // 11
+};
+constexpr int kNumP = (int)(sizeof(kP) / sizeof(kP[0]));
+int conv_dma_p_num_cfgs() { return kNumP; }
+
+bool conv_dma_p_cfg_valid(const ConvParams& p, int c) {
+    if (c < 0 || c >= kNumP) return false;
+    if ((p.Cin % 32) != 0 || (p.Kpad % 32) != 0 || p.ks > 3 || p.up != 1) return false;
+    if (p.x_bytes >= (1ull << 31) || p.w_bytes >= (1ull << 31) || p.y_bytes >= (1ull << 31)) return false;
+    if ((p.Cout & 3) || (p.y_stride & 3) || (p.y_coff & 3) || (p.res && ((p.res_stride & 3) || (p.res_coff & 3)))) return false;
+    if (p.res && p.out_f32) return false;
+    const DmaPCfg& k = kP[c];
+    if (k.BK == 64 && ((p.Cin % 64) != 0 || (p.Kpad % 64) != 0)) return false;
+    const int cpad = (p.Cout + 31) / 32 * 32;
+    if (k.BN > 32 && k.BN >= 2 * cpad) return false;
+    if (k.BN == 32 && p.Cout > 32) return false;
+    return true;
+}
+const char* conv_dma_p_kernel_name(int c) { return kP[c].name; }
+
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32>
+static hipError_t launch_p_var(const ConvParams& p, hipStream_t st) {
+    const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
+    const size_t sh = (size_t)NS * (BM + BN) * BK * 2 + 1024;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(WGM * WGN == 8 ? 2 : 4, (160 * 1024) / sh));
+    int G = (256 * per_cu) / ntiles;
+    if (G < 1) G = 1;
+    if (G > mtiles) G = mtiles;
+    auto kern = conv_dma_p_kernel<BM, BN, WGM, WGN, BK, NS, HAS_RES, OUT_F32>;
+    static bool attr = false;
+    if (!attr && sh > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3(WGM * WGN * 64), sh, st, p, mtiles, ntiles, G);
+    return hipGetLastError();
+}
+template <int BM, int BN, int WGM, int WGN, int BK, int NS>
+static hipError_t launch_p_one(const ConvParams& p, hipStream_t st) {
+    if (p.out_f32) return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, true>(p, st);
+    if (p.res) return launch_p_var<BM, BN, WGM, WGN, BK, NS, true, false>(p, st);
+    return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, false>(p, st);
+}
+
+hipError_t launch_conv_dma_p(const ConvParams& p, int c, hipStream_t st) {
+    switch (c) {
+        case 0: return launch_p_one<128, 32, 4, 1, 32, 4>(p, st);
+        case 1: return launch_p_one<128, 64, 2, 2, 32, 4>(p, st);
+        case 2: return launch_p_one<128, 128, 2, 2, 32, 4>(p, st);
+        case 3: return launch_p_one<64, 64, 2, 2, 32, 4>(p, st);
+        case 4: return launch_p_one<256, 64, 4, 2, 32, 4>(p, st);
+        case 5: return launch_p_one<256, 128, 4, 2, 32, 4>(p, st);
+        case 6: return launch_p_one<128, 128, 2, 2, 64, 3>(p, st);
+        case 7: return launch_p_one<128, 64, 2, 2, 64, 3>(p, st);
+        case 8: return launch_p_one<128, 256, 2, 4, 32, 4>(p, st);
+        case 9: return launch_p_one<64, 128, 2, 2, 64, 3>(p, st);
+        case 10: return launch_p_one<64, 64, 2, 2, 64, 4>(p, st);
+        default: return launch_p_one<128, 64, 4, 2, 64, 4>(p, st);
+    }
+}
+
+}  // namespace yp

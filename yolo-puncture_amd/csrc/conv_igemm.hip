@@ -244,6 +244,7 @@ static int conv_tile_choice(const ConvParams& p) {
 static int halo_choice(const ConvParams& p, int dtype) {
     if (dtype != DT_BF16) return -1;
     auto valid = [&](int c) {
+        if (c >= 300) return conv_dma_p_cfg_valid(p, c - 300);
         if (c >= 200) return conv_halo_p_cfg_valid(p, c - 200);
         if (c >= 100) return conv_halo_cfg_valid(p, c - 100);
         return false;
@@ -257,6 +258,7 @@ static int halo_choice(const ConvParams& p, int dtype) {
 
 const char* conv_kernel_name(const ConvParams& p, int dtype) {
     const int h = halo_choice(p, dtype);
+    if (h >= 300) return conv_dma_p_kernel_name(h - 300);
     if (h >= 200) return conv_halo_p_kernel_name(h - 200);
     if (h >= 100) return conv_halo_kernel_name(h - 100);
     if (dtype == DT_BF16 && conv_dma_supported(p)) return conv_dma_kernel_name(p);
@@ -287,6 +289,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t st) {
 
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st) {
     const int h = halo_choice(p, dtype);
+    if (h >= 300) return launch_conv_dma_p(p, h - 300, st);
     if (h >= 200) return launch_conv_halo_p(p, h - 200, st);
     if (h >= 100) return launch_conv_halo(p, h - 100, st);
     if (dtype == DT_BF16 && conv_dma_supported(p)) return launch_conv_dma(p, st);

@@ -538,6 +538,7 @@ static int autotune(yp_engine& e) {
             std::vector<int> cands;
             for (int c = 0; c < conv_halo_num_cfgs(); ++c) if (conv_halo_cfg_valid(p, c)) cands.push_back(100 + c);
             for (int c = 0; c < conv_halo_p_num_cfgs(); ++c) if (conv_halo_p_cfg_valid(p, c)) cands.push_back(200 + c);
+            for (int c = 0; c < conv_dma_p_num_cfgs(); ++c) if (conv_dma_p_cfg_valid(p, c)) cands.push_back(300 + c);
             for (int cc : cands) {
                 o.cfg = cc;
                 float tmin = 1e30f;
