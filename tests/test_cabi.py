@@ -1,0 +1,63 @@
+"""libyolop.so without a GPU: it loads, exports every symbol include/yolop.h declares, builds the same graph the
+oracle restates (weights by name and shape, FLOPs per plan), and fails loudly in the states that cannot run."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from oracle.yolov10_oracle import count_conv_flops
+from yolo_puncture_amd.engine import EXPORTS, Engine, ModelDesc, YolopError, load_library
+from yolo_puncture_amd.weights import fold_state, synthetic_state
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "yolop.h")).read()
+    declared = set(re.findall(r"\b(yp_[a-z_0-9]+)\s*\(", hdr))
+    declared.discard("yp_engine")
+    lib = load_library()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} declared in include/yolop.h but not exported"
+    assert declared == set(EXPORTS), declared ^ set(EXPORTS)
+
+
+@pytest.mark.parametrize("v,seg", [("n", True), ("s", False), ("m", True), ("b", False), ("l", False), ("x", False)])
+def test_graph_matches_folded_weights_and_flops(v, seg):
+    e = Engine(v, 80, seg, "bf16", 0)
+    exp = dict(e.expected_weights())
+    got = {}
+    for k, (w, b) in fold_state(synthetic_state(v, 80, seg)).items():
+        got[k + ".weight"], got[k + ".bias"] = tuple(w.shape), tuple(b.shape)
+    assert exp == got
+    ops = e.plan(1, 640, 640)
+    assert abs(sum(o["flops"] for o in ops) - count_conv_flops(v, seg=seg)) < 1e6
+    assert ops[0]["kind"] == "stem" and ops[-1]["kind"] == "head"
+    # rectangular inputs re-plan with recomputed shapes (1280x720 letterboxes to 384x640)
+    ops2 = e.plan(2, 384, 640)
+    assert abs(sum(o["flops"] for o in ops2) / (2 * 384 * 640) - sum(o["flops"] for o in ops) / (640 * 640)) < 1e-3 * ops[1]["flops"]
+    e.close()
+
+
+def test_errors_are_loud():
+    lib = load_library()
+    h = C.c_void_p()
+    assert lib.yp_create(C.byref(ModelDesc(ord("q"), 80, 0, 0, 300)), 0, C.byref(h)) < 0
+    assert b"variant" in lib.yp_last_error()
+    e = Engine("n", 80, False, "bf16", 0)
+    with pytest.raises(YolopError):
+        e.plan(1, 100, 100)                           # not multiples of 32
+    t = torch.zeros(3)
+    shp = (C.c_int64 * 1)(3)
+    assert lib.yp_set_weight(e._h, b"model.0.nonsense", C.c_void_p(t.data_ptr()), shp, 1) < 0
+    assert lib.yp_set_weight(e._h, b"model.0.bias", C.c_void_p(t.data_ptr()), shp, 1) < 0      # wrong shape
+    with pytest.raises(YolopError):
+        e.finalize()                                  # weights missing
+    e.load_state(synthetic_state("n", 80, False))
+    if not torch.cuda.is_available():
+        with pytest.raises(YolopError, match="no HIP device"):
+            e.finalize()                              # no GPU here -> no silent CPU fallback
+        assert lib.yp_forward(e._h, None, 1, 64, 64, None, None, None, None) < 0
+    e.close()

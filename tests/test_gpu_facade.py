@@ -1,0 +1,128 @@
+"""GPU tests of the drop-in surface: `YOLO(path).predict(...)`, the mask tail and `auto_segment`, against the oracle
+pipeline on the same frames. fp32 engine mode, so the comparison is tight (boxes 5e-3 px; masks: pixels whose logit is
+within 1e-4 of zero may differ - the fraction is bounded)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_case, nchw_to_nhwc, rand_image
+from oracle import postprocess_oracle as po
+from oracle.yolov10_oracle import Oracle
+from yolo_puncture_amd.weights import read_ultralytics_pt, save_as_ultralytics_pt
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ckpt(tmp_path_factory):
+    """A calibrated v10-N-seg checkpoint on disk in the ultralytics layout (fp16 storage, as released weights are),
+    calibrated on the letterboxed version of the test frame."""
+    frame = rand_image((1, 360, 640, 3), seed=7)[0].numpy()              # a 640x360 BGR frame -> letterbox 384x640
+    boxed, _ = po.letterbox(frame)
+    from helpers import _CalibOracle
+    from yolo_puncture_amd.weights import synthetic_state
+    st0 = synthetic_state("n", 80, True, seed=3, cls_bias=-1.0)
+    co = _CalibOracle(st0, "n", 80, True, "fp32")
+    co.forward(torch.from_numpy(boxed[None]))
+    st = {}
+    for name, (w, b) in co.w.items():
+        if f"{name}.conv.weight" in st0:
+            c2 = w.shape[0]
+            st.update({f"{name}.conv.weight": w, f"{name}.bn.weight": torch.ones(c2), f"{name}.bn.bias": b,
+                       f"{name}.bn.running_mean": torch.zeros(c2), f"{name}.bn.running_var": torch.full((c2,), 1 - 1e-3)})
+        else:
+            st.update({f"{name}.weight": w, f"{name}.bias": b})
+    p = str(tmp_path_factory.mktemp("w") / "v10n-seg-calib.pt")
+    save_as_ultralytics_pt(st, p)
+    return p, frame
+
+
+def _oracle_predict(path, frame, conf, retina):
+    st, meta = read_ultralytics_pt(path)
+    boxed, _ = po.letterbox(frame)
+    o = Oracle(st, meta["variant"], meta["nc"], meta["seg"], "fp32").forward(torch.from_numpy(boxed[None]))
+    det = o["det"][0]
+    keep = det[:, 4] > conf
+    det = det[keep]
+    boxes_in = det[:, :4].clone()
+    H, W = boxed.shape[:2]
+    oh, ow = frame.shape[:2]
+    det = det.clone()
+    det[:, :4] = po.scale_boxes((H, W), det[:, :4], (oh, ow))
+    cf = o["coeff"][0][keep]
+    if retina:
+        m = po.process_mask_native(o["proto"][0], cf, det[:, :4], (oh, ow))
+    else:
+        m = po.process_mask(o["proto"][0], cf, boxes_in, (H, W))
+    return det, m
+
+
+@pytest.mark.parametrize("retina", [True, False])
+def test_predict_matches_oracle_pipeline(ckpt, retina):
+    from yolo_puncture_amd import YOLO
+    path, frame = ckpt
+    conf = 0.3
+    model = YOLO(path, dtype="fp32")
+    assert model.task == "segment"
+    res = model.predict(source=frame, conf=conf, retina_masks=retina, device="cuda")
+    assert isinstance(res, list) and len(res) == 1
+    r = res[0]
+    det, masks = _oracle_predict(path, frame, conf, retina)
+    n = det.shape[0]
+    assert n >= 3, "test case should produce detections"
+    b = r.boxes.cpu().numpy()
+    assert len(b.cls) == n
+    assert np.array_equal(b.cls, det[:, 5].numpy())
+    assert np.abs(b.xyxy - det[:, :4].numpy()).max() < 5e-3 and np.abs(b.conf - det[:, 4].numpy()).max() < 1e-4
+    assert len(r.masks) == n and tuple(r.masks.data.shape[1:]) == tuple(masks.shape[1:])
+    diff = (r.masks.data.cpu() != masks).float().mean().item()
+    assert diff < 2e-4, diff
+    poly = r.masks.xy[int(np.argmax(b.conf))]                        # what app.py:95-101 does
+    assert poly.dtype == np.float32 and poly.ndim == 2 and poly.shape[1] == 2
+    # a PIL source (app.py:49) and a path-free empty result (conf too high -> masks is None, boxes empty)
+    from PIL import Image
+    r2 = model.predict(source=Image.fromarray(frame[:, :, ::-1].copy()), conf=conf, retina_masks=retina)[0]
+    assert np.array_equal(r2.boxes.cpu().numpy().cls, b.cls)
+    r3 = model.predict(frame, conf=0.99999, retina_masks=retina)[0]
+    assert len(r3.boxes.cls) == 0 and r3.masks is None
+
+
+def test_auto_segment_matches_reference_semantics(ckpt):
+    from yolo_puncture_amd import YOLO, auto_segment
+    path, frame = ckpt
+    model = YOLO(path, dtype="fp32")
+    model.model.to("cuda")                                             # yolo_with_deva.py:129-130, every frame
+    conf = 0.9
+    det, masks = _oracle_predict(path, frame, conf, True)
+    # lower the bar if this synthetic net has nothing above 0.9: the reference hard-codes conf=0.9 (yolo_with_deva.py:51)
+    ids, info = auto_segment({"MIN_AREA_THRESHOLD": 100}, frame, model, min_side=0, suppress_small_mask=True)
+    want_ids, want_info = po.auto_segment_oracle(masks if len(masks) else None, det[:, 4], det[:, 5], frame.shape[:2], True, 100)
+    assert ids.dtype == torch.int64 and tuple(ids.shape) == frame.shape[:2] and ids.is_cuda
+    assert (ids.cpu() != want_ids).float().mean().item() < 2e-4
+    assert [(i.id, i.category_id) for i in info] == [(a, c) for a, _, c in want_info]
+    assert np.allclose([i.score for i in info], [s for _, s, _ in want_info], atol=1e-4)
+
+
+def test_mask_kernels_bit_level(ckpt):
+    """yp_masks alone on the engine's own prototypes: GEMM -> bilinear -> crop -> >0 and the id paint, n = 0, 1, many,
+    boxes touching the borders, with and without small-mask suppression."""
+    from yolo_puncture_amd.engine import Engine
+    st, im = make_case("n", 80, True, 0, (2, 96, 160))
+    eng = Engine("n", 80, True, "fp32", 0, state=st)
+    out = eng.forward(im.cuda())
+    torch.cuda.synchronize()
+    proto = eng.proto()                                               # [B,Hp,Wp,32] fp32 host copy
+    g = torch.Generator().manual_seed(0)
+    for b, (oh, ow) in ((0, (90, 160)), (1, (96, 160)), (1, (200, 333))):
+        for n in (0, 1, 7):
+            coeff = torch.randn(n, 32, generator=g)
+            boxes = torch.rand(n, 4, generator=g) * torch.tensor([ow / 2, oh / 2, ow / 2, oh / 2]) + torch.tensor([0, 0, ow / 2, oh / 2])
+            if n:
+                boxes[0] = torch.tensor([0., 0., float(ow), float(oh)])
+            m, ids, kept = eng.masks(b, coeff.cuda(), boxes.cuda(), (oh, ow), retina=True, want_ids=True, suppress_small=True, min_area=50)
+            want = po.process_mask_native(proto[b].permute(2, 0, 1), coeff, boxes, (oh, ow)) if n else torch.zeros(0, oh, ow)
+            assert (m.cpu().float() != want).float().mean().item() < 2e-4 if n else m.shape[0] == 0
+            wi, winfo = po.auto_segment_oracle(m.cpu().float() if n else None, torch.ones(n), torch.zeros(n), (oh, ow), True, 50)
+            assert torch.equal(ids.cpu(), wi)
+            assert [k for k in kept.cpu().tolist() if k > 0] == [a for a, _, _ in winfo]
+    eng.close()

@@ -1,0 +1,156 @@
+"""Host logic of the product package (no GPU): weight loading/folding, LetterBox & friends against the oracle's
+independent restatement, the Results/Boxes/Masks surface, error behaviour of the facade."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import make_case
+from oracle import postprocess_oracle as po
+from oracle.yolov10_oracle import Oracle, expected_state
+from yolo_puncture_amd import hostops
+from yolo_puncture_amd.weights import (fold_state, guess_variant, read_ultralytics_pt, save_as_ultralytics_pt,
+                                       synthetic_state)
+
+
+@pytest.mark.parametrize("v,seg", [("n", False), ("s", True), ("m", False), ("x", False)])
+def test_synthetic_state_has_the_checkpoint_layout(v, seg):
+    st = synthetic_state(v, 80, seg)
+    exp = dict(expected_state(v, 80, seg))
+    assert set(st) == set(exp)
+    assert all(tuple(st[k].shape) == exp[k] for k in st)
+    assert guess_variant(st) == v
+
+
+def test_fold_matches_oracle_fuse():
+    st, _ = make_case("s", 80, True, 0, (1, 64, 64))
+    folded = fold_state(st)
+    orc = Oracle(st, "s", 80, True, "fp32")
+    assert set(folded) == set(orc.w)
+    for k, (w, b) in folded.items():
+        assert torch.equal(w, orc.w[k][0]) and torch.equal(b, orc.w[k][1]), k
+    assert not any(k.startswith("model.23.cv2.") for k in folded)
+
+
+def test_pt_reader_dict_form(tmp_path):
+    st = synthetic_state("n", 3, True)
+    p = str(tmp_path / "w.pt")
+    save_as_ultralytics_pt(st, p)
+    got, meta = read_ultralytics_pt(p)
+    assert meta["variant"] == "n" and meta["seg"] and meta["nc"] == 3
+    assert set(got) == set(st) and torch.allclose(got["model.0.conv.weight"], st["model.0.conv.weight"].half().float())
+    with pytest.raises(FileNotFoundError):
+        read_ultralytics_pt(str(tmp_path / "missing.pt"))
+
+
+def test_pt_reader_full_module_pickle_without_ultralytics(tmp_path):
+    """Released checkpoints pickle the whole nn.Module by class reference. Fabricate one whose classes live
+    in a module path that is NOT importable at load time and read it back through the stub unpickler."""
+    import sys
+    import types
+    modname = "ultralytics.nn.modules.fake_for_test"
+    for part in ("ultralytics", "ultralytics.nn", "ultralytics.nn.modules", modname):
+        sys.modules.setdefault(part, types.ModuleType(part))
+    fake = sys.modules[modname]
+
+    class Blob:                                    # mimics nn.Module's pickled __dict__
+        pass
+
+    Blob.__module__, Blob.__qualname__ = modname, "Blob"
+    fake.Blob = Blob
+
+    def mod(params=None, buffers=None, children=None):
+        m = Blob()
+        m._parameters, m._buffers, m._modules = dict(params or {}), dict(buffers or {}), dict(children or {})
+        return m
+
+    st = synthetic_state("n", 80, False)
+    root = mod()
+    for k, v in st.items():                        # build the module tree from the dotted names
+        parts = k.split(".")
+        node = root
+        for p_ in parts[:-1]:
+            node = node._modules.setdefault(p_, mod())
+        (node._buffers if "running" in parts[-1] else node._parameters)[parts[-1]] = v.half()
+    root.names = {0: "needle"}
+    root.yaml = {"nc": 80}
+    path = str(tmp_path / "full.pt")
+    torch.save({"model": root, "ema": None, "date": "x"}, path)
+    for part in (modname,):
+        del sys.modules[part]                      # the class can no longer be imported: only stubs can load it
+    got, meta = read_ultralytics_pt(path)
+    assert set(got) == set(st) and meta["variant"] == "n" and meta["names"] == {0: "needle"}
+
+
+def test_letterbox_matches_oracle_restatement():
+    rng = np.random.default_rng(0)
+    for (h, w) in ((720, 1280), (1080, 810), (333, 517), (640, 640), (64, 48)):
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        a, ga = hostops.letterbox(img)
+        b, gb = po.letterbox(img)
+        assert a.shape == b.shape and ga["top"] == gb["top"] and ga["left"] == gb["left"]
+        assert np.array_equal(a, b)
+        assert a.shape[0] % 32 == 0 and a.shape[1] % 32 == 0
+
+
+def test_scale_boxes_matches_oracle():
+    b = torch.tensor([[12.5, 30., 600., 380.], [-5., -5., 700., 500.]])
+    assert torch.allclose(hostops.scale_boxes_t((384, 640), b, (720, 1280)), po.scale_boxes((384, 640), b, (720, 1280)))
+
+
+def test_contours():
+    m = np.zeros((12, 14), bool)
+    m[3:8, 4:11] = True
+    assert hostops.largest_external_contour(m).tolist() == [[4, 3], [10, 3], [10, 7], [4, 7]]
+    m[0, 0] = True                                  # a second, smaller blob is ignored ("largest")
+    assert hostops.largest_external_contour(m).shape[0] == 4
+    assert hostops.largest_external_contour(np.zeros((5, 5), bool)).shape == (0, 2)
+    one = np.zeros((5, 5), bool)
+    one[2, 3] = True
+    assert hostops.largest_external_contour(one).tolist() == [[3, 2]]
+    # a ring: only the EXTERNAL border
+    ring = np.zeros((9, 9), bool)
+    ring[1:8, 1:8] = True
+    ring[3:6, 3:6] = False
+    assert hostops.largest_external_contour(ring).tolist() == [[1, 1], [7, 1], [7, 7], [1, 7]]
+
+
+def test_sources_and_results_surface():
+    from PIL import Image
+    from yolo_puncture_amd.predictor import Boxes, Masks, Results
+    rgb = np.zeros((4, 6, 3), np.uint8)
+    rgb[..., 0] = 200                                # red in RGB
+    imgs, _ = hostops.load_sources(Image.fromarray(rgb))
+    assert imgs[0][0, 0].tolist() == [0, 0, 200]     # PIL -> BGR
+    arr = np.zeros((4, 6, 3), np.uint8)
+    assert hostops.load_sources(arr)[0][0] is arr    # ndarray taken as-is (BGR assumed, never "fixed")
+    with pytest.raises(TypeError):
+        hostops.load_sources(np.zeros((4, 6), np.uint8))
+    d = torch.tensor([[10., 20., 30., 60., 0.9, 2.], [0., 0., 8., 8., 0.5, 1.]])
+    bx = Boxes(d, (100, 200))
+    n = bx.cpu().numpy()
+    assert n.cls.shape == (2,) and np.allclose(n.xywhn[0], [0.1, 0.4, 0.1, 0.4]) and int(np.argmax(n.conf)) == 0
+    assert len(Boxes(d[:0], (100, 200)).cls) == 0
+    mk = Masks(torch.zeros(2, 100, 200), (100, 200))
+    mk.data[0, 10:20, 30:50] = 1
+    assert len(mk) == 2 and mk.xy[0].dtype == np.float32 and mk.xy[0].shape == (4, 2) and mk.xy[1].shape == (0, 2)
+    r = Results(np.zeros((100, 200, 3), np.uint8), bx, None, {0: "a"})
+    assert r.masks is None and len(r) == 2 and r.cpu().numpy().boxes.xyxy.shape == (2, 4)
+
+
+def test_yolo_constructor_errors(tmp_path):
+    from yolo_puncture_amd.predictor import YOLO
+    with pytest.raises(FileNotFoundError):
+        YOLO(str(tmp_path / "nope.pt"))
+    bad = str(tmp_path / "bad.pt")
+    torch.save({"model": {"foo.weight": torch.zeros(2)}}, bad)
+    with pytest.raises(ValueError):
+        YOLO(bad)
+    y = YOLO("synthetic:n-seg")
+    assert y.task == "segment" and y.variant == "n"
+    with pytest.raises(ValueError):
+        y.model.to("cpu")                            # the engine is GPU-only; nothing falls back
+    with pytest.raises(ValueError):
+        y.predict(None)

@@ -1,0 +1,198 @@
+"""Host-side steps around the engine: source loading, LetterBox, box rescale, mask -> polygon.
+
+These sit on the CPU in the reference too (cv2 / numpy inside ultralytics' predictor; SURVEY.md A.5-A.7 [U]) and are
+"next" rows of the scope table for a GPU version. cv2 is not available offline, so the 8-bit
+INTER_LINEAR resize and the external-contour trace are restated here from the public OpenCV algorithms.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+
+# ---- sources (A.5 step 1) --------------------------------------------------------------------------------------------
+def _one_source(src) -> Tuple[np.ndarray, str]:
+    if isinstance(src, np.ndarray):
+        if src.ndim != 3 or src.shape[2] != 3 or src.dtype != np.uint8:
+            raise TypeError(f"ndarray source must be HxWx3 uint8 (BGR), got {src.shape} {src.dtype}")
+        return src, ""                                    # ndarray => taken as BGR, never auto-corrected (SURVEY C-6)
+    if isinstance(src, (str, os.PathLike)):
+        from PIL import Image
+        p = os.fspath(src)
+        if not os.path.isfile(p):
+            raise FileNotFoundError(p)
+        with Image.open(p) as im:
+            rgb = np.asarray(im.convert("RGB"))
+        return np.ascontiguousarray(rgb[:, :, ::-1]), p
+    if hasattr(src, "convert") and hasattr(src, "size"):   # PIL.Image -> RGB -> BGR (yolo_seg/app.py:49)
+        rgb = np.asarray(src.convert("RGB"))
+        return np.ascontiguousarray(rgb[:, :, ::-1]), ""
+    if isinstance(src, torch.Tensor):
+        raise TypeError("tensor sources are not part of the reference's call sites; pass ndarray / PIL / path")
+    raise TypeError(f"unsupported source type {type(src)}")
+
+
+def load_sources(source) -> Tuple[List[np.ndarray], List[str]]:
+    items = list(source) if isinstance(source, (list, tuple)) else [source]
+    if not items:
+        raise ValueError("empty source list")
+    pairs = [_one_source(s) for s in items]
+    return [p[0] for p in pairs], [p[1] for p in pairs]
+
+
+# ---- LetterBox (A.5 step 2) ------------------------------------------------------------------------------------------
+def letterbox_geometry(h0: int, w0: int, new_shape: int = 640, stride: int = 32, auto: bool = True) -> dict:
+    r = min(new_shape / h0, new_shape / w0)
+    nw, nh = int(round(w0 * r)), int(round(h0 * r))
+    dw, dh = new_shape - nw, new_shape - nh
+    if auto:
+        dw, dh = dw % stride, dh % stride
+    dw /= 2
+    dh /= 2
+    top, bottom = int(round(dh - 0.1)), int(round(dh + 0.1))
+    left, right = int(round(dw - 0.1)), int(round(dw + 0.1))
+    return dict(r=r, new_w=nw, new_h=nh, top=top, bottom=bottom, left=left, right=right,
+                out_h=nh + top + bottom, out_w=nw + left + right)
+
+
+def _axis_coeffs(n_dst: int, n_src: int):
+    scale = n_src / n_dst
+    f = ((np.arange(n_dst, dtype=np.float64) + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    lo, hi = s < 0, s >= n_src - 1
+    s[lo], f[lo] = 0, 0
+    s[hi], f[hi] = n_src - 1, 0
+    a1 = np.rint(f * 2048).astype(np.int64)
+    a0 = np.rint((np.float32(1.0) - f) * 2048).astype(np.int64)
+    return s, np.minimum(s + 1, n_src - 1), a0, a1
+
+
+def resize_linear_u8(img: np.ndarray, new_w: int, new_h: int) -> np.ndarray:
+    """8-bit bilinear resize in OpenCV's fixed-point form (11-bit coefficients; vertical pass
+    ((b0*(S0>>4))>>16 + (b1*(S1>>4))>>16 + 2)>>2). Restated, not verified against cv2 (absent offline)."""
+    h0, w0 = img.shape[:2]
+    if (h0, w0) == (new_h, new_w):
+        return img
+    x0, x1, ax0, ax1 = _axis_coeffs(new_w, w0)
+    y0, y1, ay0, ay1 = _axis_coeffs(new_h, h0)
+    src = img.astype(np.int64)
+    hrow = src[:, x0, :] * ax0[None, :, None] + src[:, x1, :] * ax1[None, :, None]
+    out = (((ay0[:, None, None] * (hrow[y0] >> 4)) >> 16) + ((ay1[:, None, None] * (hrow[y1] >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+def letterbox(img_bgr: np.ndarray, new_shape: int = 640, stride: int = 32, auto: bool = True):
+    g = letterbox_geometry(img_bgr.shape[0], img_bgr.shape[1], new_shape, stride, auto)
+    im = resize_linear_u8(img_bgr, g["new_w"], g["new_h"])
+    out = np.full((g["out_h"], g["out_w"], 3), 114, dtype=np.uint8)
+    out[g["top"]:g["top"] + g["new_h"], g["left"]:g["left"] + g["new_w"]] = im
+    return out, g
+
+
+# ---- boxes (A.6 step 3) ----------------------------------------------------------------------------------------------
+def scale_boxes_t(img1_hw: Sequence[int], boxes: torch.Tensor, img0_hw: Sequence[int]) -> torch.Tensor:
+    """undo letterbox pad/gain, clamp to the original image (ops.scale_boxes + clip_boxes)."""
+    gain = min(img1_hw[0] / img0_hw[0], img1_hw[1] / img0_hw[1])
+    padx = round((img1_hw[1] - img0_hw[1] * gain) / 2 - 0.1)
+    pady = round((img1_hw[0] - img0_hw[0] * gain) / 2 - 0.1)
+    b = boxes.clone()
+    b[:, 0] -= padx
+    b[:, 2] -= padx
+    b[:, 1] -= pady
+    b[:, 3] -= pady
+    b /= gain
+    b[:, 0].clamp_(0, img0_hw[1])
+    b[:, 2].clamp_(0, img0_hw[1])
+    b[:, 1].clamp_(0, img0_hw[0])
+    b[:, 3].clamp_(0, img0_hw[0])
+    return b
+
+
+def scale_coords(img1_hw: Sequence[int], coords: np.ndarray, img0_hw: Sequence[int]) -> np.ndarray:
+    """polygon points from the letterboxed frame to the original image (ops.scale_coords)."""
+    gain = min(img1_hw[0] / img0_hw[0], img1_hw[1] / img0_hw[1])
+    padx = (img1_hw[1] - img0_hw[1] * gain) / 2
+    pady = (img1_hw[0] - img0_hw[0] * gain) / 2
+    c = coords.astype(np.float32).copy()
+    c[:, 0] = np.clip((c[:, 0] - padx) / gain, 0, img0_hw[1])
+    c[:, 1] = np.clip((c[:, 1] - pady) / gain, 0, img0_hw[0])
+    return c
+
+
+# ---- Masks.xy (A.7): external contour of the largest blob, straight runs compressed ----------------------------------
+_DIRS = [(0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1)]   # (dy,dx), clockwise from east
+
+
+def _trace_outer(mask: np.ndarray, sy: int, sx: int) -> List[Tuple[int, int]]:
+    """Moore-neighbour boundary trace (8-connectivity) of the blob containing (sy,sx), which must be its first pixel
+    in raster order; Jacob's stopping criterion."""
+    H, W = mask.shape
+
+    def on(y, x):
+        return 0 <= y < H and 0 <= x < W and mask[y, x]
+
+    pts = [(sx, sy)]
+    cy, cx, d = sy, sx, 6            # we "arrived" from the north-west side: start searching at north
+    start_d = None
+    for _ in range(4 * H * W + 8):
+        found = False
+        for k in range(8):
+            nd = (d + k) % 8
+            ny, nx = cy + _DIRS[nd][0], cx + _DIRS[nd][1]
+            if on(ny, nx):
+                if start_d is None:
+                    start_d = nd
+                elif (cy, cx) == (sy, sx) and nd == start_d:
+                    return pts[:-1] if len(pts) > 1 else pts
+                cy, cx = ny, nx
+                pts.append((cx, cy))
+                d = (nd + 6) % 8 if (nd % 2 == 0) else (nd + 5) % 8   # restart at the background pixel examined last
+                found = True
+                break
+        if not found:
+            return pts                  # isolated pixel
+    return pts
+
+
+def _compress(pts: List[Tuple[int, int]]) -> np.ndarray:
+    """CHAIN_APPROX_SIMPLE: keep only the end points of horizontal / vertical / diagonal runs."""
+    n = len(pts)
+    if n <= 2:
+        return np.asarray(pts, dtype=np.int32).reshape(-1, 2)
+    keep = []
+    for i in range(n):
+        px, py = pts[i - 1]
+        cx, cy = pts[i]
+        nx, ny = pts[(i + 1) % n]
+        if (cx - px, cy - py) != (nx - cx, ny - cy):
+            keep.append((cx, cy))
+    if not keep:
+        keep = [pts[0]]
+    return np.asarray(keep, dtype=np.int32)
+
+
+def largest_external_contour(mask: np.ndarray) -> np.ndarray:
+    """[m,2] (x,y) int32 polygon: the external contour with the most points (ultralytics masks2segments 'largest')."""
+    from scipy import ndimage
+    mask = np.asarray(mask, dtype=bool)
+    lab, n = ndimage.label(mask, structure=np.ones((3, 3), dtype=int))
+    best = np.zeros((0, 2), dtype=np.int32)
+    if n == 0:
+        return best
+    first = ndimage.find_objects(lab)
+    for k in range(1, n + 1):
+        sl = first[k - 1]
+        sub = lab[sl] == k
+        ys, xs = np.nonzero(sub)
+        sy = ys.min()
+        sx = xs[ys == sy].min()
+        pts = _trace_outer(sub, int(sy), int(sx))
+        poly = _compress(pts)
+        poly = poly + np.asarray([sl[1].start, sl[0].start], dtype=np.int32)
+        if poly.shape[0] > best.shape[0]:
+            best = poly
+    return best

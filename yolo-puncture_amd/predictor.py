@@ -1,0 +1,322 @@
+"""`YOLO(...).predict(...)` facade over the MI355X engine: the exact Python surface the reference's callers use.
+
+Call sites mirrored (reference = /root/reference):
+    YOLO(path)                                         yolo_seg/app.py:45, yolo_seg/yolo_with_deva.py:226,
+                                                       dev_tools/auto_speed_calc.py:40, dev_tools/classify/cls_bbox_dataset_generate.py:66
+    .predict(source=, conf=, retina_masks=, device=)   yolo_seg/app.py:49,91 ; yolo_seg/yolo_with_deva.py:51 (positional source) ;
+                                                       dev_tools/auto_speed_calc.py:62 ; dev_tools/classify/cls_bbox_dataset_generate.py:48
+    results[0].boxes.cpu().numpy() / .xyxy .conf .cls  yolo_seg/app.py:92-98 ; .xywhn cls_bbox_dataset_generate.py:52
+    results[0].masks.xy[i] / .data[i] / len(masks)     yolo_seg/app.py:50,101 ; yolo_seg/yolo_with_deva.py:61-68
+    yolo.model.parameters() / yolo.model.to(device)    yolo_seg/yolo_with_deva.py:42,130
+Semantics follow SURVEY.md Appendix A.5-A.7 [U] (ultralytics is not vendored in the reference).
+The network itself runs only through libyolop.so (engine.py); there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import hostops
+from .engine import Engine
+from .weights import read_ultralytics_pt, synthetic_state
+
+_ENGINE_CACHE: Dict[tuple, Engine] = {}
+
+
+class Boxes:
+    """[n,6] rows = x1,y1,x2,y2 (original-image pixels), conf, cls; sorted by conf descending."""
+
+    def __init__(self, data, orig_shape: Tuple[int, int]):
+        self.data = data
+        self.orig_shape = tuple(orig_shape)
+
+    def _new(self, data):
+        return Boxes(data, self.orig_shape)
+
+    def cpu(self):
+        return self._new(self.data.cpu() if isinstance(self.data, torch.Tensor) else self.data)
+
+    def numpy(self):
+        return self._new(self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else self.data)
+
+    def to(self, *a, **k):
+        return self._new(self.data.to(*a, **k) if isinstance(self.data, torch.Tensor) else self.data)
+
+    def __len__(self):
+        return int(self.data.shape[0])
+
+    def __getitem__(self, i):
+        d = self.data[i]
+        return self._new(d.reshape(-1, 6) if d.ndim == 1 else d)
+
+    @property
+    def xyxy(self):
+        return self.data[:, :4]
+
+    @property
+    def conf(self):
+        return self.data[:, 4]
+
+    @property
+    def cls(self):
+        return self.data[:, 5]
+
+    @property
+    def xywh(self):
+        x = self.xyxy
+        cat = torch.stack if isinstance(x, torch.Tensor) else np.stack
+        return cat(((x[:, 0] + x[:, 2]) / 2, (x[:, 1] + x[:, 3]) / 2, x[:, 2] - x[:, 0], x[:, 3] - x[:, 1]), -1)
+
+    @property
+    def xyxyn(self):
+        h, w = self.orig_shape
+        x = self.xyxy
+        s = x.new_tensor([w, h, w, h]) if isinstance(x, torch.Tensor) else np.asarray([w, h, w, h], dtype=x.dtype)
+        return x / s
+
+    @property
+    def xywhn(self):
+        h, w = self.orig_shape
+        x = self.xywh
+        s = x.new_tensor([w, h, w, h]) if isinstance(x, torch.Tensor) else np.asarray([w, h, w, h], dtype=x.dtype)
+        return x / s
+
+
+class Masks:
+    """.data: float {0,1} [n,H,W] (H,W = original image when retina_masks else the letterboxed input);
+    .xy: one float32 [m,2] polygon per mask (largest external contour, pixels of the original image)."""
+
+    def __init__(self, data: torch.Tensor, orig_shape: Tuple[int, int]):
+        self.data = data
+        self.orig_shape = tuple(orig_shape)
+        self._xy = None
+
+    def cpu(self):
+        m = Masks(self.data.cpu(), self.orig_shape)
+        m._xy = self._xy
+        return m
+
+    def numpy(self):
+        m = Masks(self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else self.data, self.orig_shape)
+        m._xy = self._xy
+        return m
+
+    def __len__(self):
+        return int(self.data.shape[0])
+
+    def __getitem__(self, i):
+        d = self.data[i]
+        return Masks(d[None] if d.ndim == 2 else d, self.orig_shape)
+
+    @property
+    def xy(self) -> List[np.ndarray]:
+        if self._xy is None:
+            d = self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else np.asarray(self.data)
+            mh, mw = d.shape[1:]
+            out = []
+            for m in d:
+                poly = hostops.largest_external_contour(m > 0.5)
+                if poly.shape[0] and (mh, mw) != self.orig_shape:
+                    poly = hostops.scale_coords((mh, mw), poly, self.orig_shape)
+                out.append(poly.astype(np.float32))
+            self._xy = out
+        return self._xy
+
+
+class Results:
+    def __init__(self, orig_img: np.ndarray, boxes: Boxes, masks: Optional[Masks], names: Dict[int, str], path: str = ""):
+        self.orig_img = orig_img
+        self.orig_shape = tuple(orig_img.shape[:2])
+        self.boxes = boxes
+        self.masks = masks
+        self.names = names
+        self.path = path
+
+    def __len__(self):
+        return len(self.boxes)
+
+    def cpu(self):
+        return Results(self.orig_img, self.boxes.cpu(), self.masks.cpu() if self.masks is not None else None, self.names, self.path)
+
+    def numpy(self):
+        return Results(self.orig_img, self.boxes.numpy(), self.masks.numpy() if self.masks is not None else None, self.names, self.path)
+
+
+class _ModelHandle:
+    """What callers touch through `yolo.model`: `.parameters()` for the device and an idempotent `.to()`
+    (reference yolo_seg/yolo_with_deva.py:42,129-130 moves the model every frame)."""
+
+    def __init__(self, owner: "YOLO"):
+        self._owner = owner
+        self.names = owner.names
+
+    def parameters(self):
+        yield self._owner._device_token()
+
+    def to(self, device=None, *a, **k):
+        self._owner._set_device(device)
+        return self
+
+    def eval(self):
+        return self
+
+    def fuse(self, *a, **k):
+        return self
+
+
+class YOLO:
+    """Drop-in for `ultralytics.YOLO` on the predict path of YOLOv10 detect / v10-seg checkpoints.
+
+    model: path to an ultralytics-layout `.pt` (read without ultralytics, weights.py), or "synthetic:<n|s|m|b|l|x>[-seg]"
+    (seeded weights, for tests/benchmarks: no checkpoint exists offline)."""
+
+    def __init__(self, model: Union[str, os.PathLike] = "yolov10s.pt", task: Optional[str] = None, dtype: str = "bf16",
+                 device: Optional[Union[int, str, torch.device]] = None, nc: int = 80, seed: int = 0):
+        self.ckpt_path = str(model)
+        self.dtype = dtype
+        if self.ckpt_path.startswith("synthetic:"):
+            spec = self.ckpt_path.split(":", 1)[1]
+            self.variant, self.seg = spec.split("-")[0], spec.endswith("-seg")
+            self.nc = nc
+            self._state = synthetic_state(self.variant, nc, self.seg, seed=seed)
+            self.names = {i: str(i) for i in range(nc)}
+        else:
+            if not os.path.isfile(self.ckpt_path):
+                raise FileNotFoundError(f"{self.ckpt_path}: no such checkpoint (nothing is downloaded)")
+            st, meta = read_ultralytics_pt(self.ckpt_path)
+            if meta.get("variant") is None or meta.get("nc") is None:
+                raise ValueError(f"{self.ckpt_path}: not a YOLOv10 checkpoint this engine understands "
+                                 "(v8/11 trunks are not built yet)")
+            self.variant, self.seg, self.nc = meta["variant"], bool(meta["seg"]), int(meta["nc"])
+            self._state = st
+            names = meta.get("names")
+            self.names = dict(names) if isinstance(names, dict) else {i: str(i) for i in range(self.nc)}
+        if task == "segment" and not self.seg:
+            raise ValueError("task='segment' but the checkpoint has no Proto/cv4 head")
+        self.task = "segment" if self.seg else "detect"
+        self._dev_index: Optional[int] = None
+        self._set_device(device)
+        self.model = _ModelHandle(self)
+
+    # -- device / engine -----------------------------------------------------------------------------------------
+    def _set_device(self, device) -> None:
+        if device is None or device == "":
+            idx = self._dev_index if self._dev_index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        else:
+            d = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+            if d.type != "cuda":
+                raise ValueError(f"device={device!r}: this engine runs on MI355X GPUs only (device='cuda' / 'cuda:N' / N)")
+            idx = d.index if d.index is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+        self._dev_index = int(idx)
+
+    def _device_token(self) -> torch.Tensor:
+        return torch.empty(0, device=torch.device("cuda", self._dev_index))
+
+    def _engine(self) -> Engine:
+        # the reference rebuilds the model on every request (yolo_seg/app.py:45): keep engines per (ckpt, mtime, ...)
+        try:
+            mt = os.path.getmtime(self.ckpt_path)
+        except OSError:
+            mt = 0.0
+        key = (self.ckpt_path, mt, self.variant, self.nc, self.seg, self.dtype, self._dev_index)
+        eng = _ENGINE_CACHE.get(key)
+        if eng is None:
+            eng = Engine(self.variant, self.nc, self.seg, self.dtype, self._dev_index, state=self._state)
+            _ENGINE_CACHE[key] = eng
+        return eng
+
+    # -- predict ---------------------------------------------------------------------------------------------------
+    def __call__(self, source=None, **kw):
+        return self.predict(source, **kw)
+
+    def predict(self, source=None, conf: float = 0.25, retina_masks: bool = False, device=None, imgsz: int = 640,
+                max_det: int = 300, stream: bool = False, verbose: bool = False, **ignored) -> List[Results]:
+        if source is None:
+            raise ValueError("predict() needs a source (ndarray BGR HWC uint8, PIL.Image, path or a list of them)")
+        if device is not None:
+            self._set_device(device)
+        imgs, paths = hostops.load_sources(source)                    # list of BGR uint8 HWC (ndarray => taken as BGR)
+        eng = self._engine()
+        dev = torch.device("cuda", self._dev_index)
+        results: List[Results] = []
+        # frames that letterbox to the same shape run as one batch
+        groups: Dict[Tuple[int, int], List[int]] = {}
+        lb = []
+        for i, im in enumerate(imgs):
+            boxed, geo = hostops.letterbox(im, imgsz)
+            lb.append((boxed, geo))
+            groups.setdefault(boxed.shape[:2], []).append(i)
+        out_by_index: Dict[int, Results] = {}
+        for (H, W), idxs in groups.items():
+            batch = torch.from_numpy(np.stack([lb[i][0] for i in idxs])).to(dev, non_blocking=True)
+            out = eng.forward(batch)
+            det = out["det"]
+            for bi, i in enumerate(idxs):
+                oh, ow = imgs[i].shape[:2]
+                d = det[bi]
+                keep = d[:, 4] > conf                                   # strict, A.6 step 2
+                d = d[keep][:max_det]
+                n = int(d.shape[0])
+                boxes_in = d[:, :4].clone()                              # letterboxed-input pixels
+                d = d.clone()
+                d[:, :4] = hostops.scale_boxes_t((H, W), d[:, :4], (oh, ow))
+                masks = None
+                if self.seg and n > 0:
+                    cf = out["coeff"][bi][keep][:max_det]
+                    if retina_masks:
+                        m, _, _ = eng.masks(bi, cf, d[:, :4], (oh, ow), retina=True)
+                    else:
+                        m, _, _ = eng.masks(bi, cf, boxes_in, (H, W), retina=False)
+                    masks = Masks(m.to(torch.float32), (oh, ow))
+                out_by_index[i] = Results(imgs[i], Boxes(d, (oh, ow)), masks, self.names, paths[i])
+        for i in range(len(imgs)):
+            results.append(out_by_index[i])
+        return results
+
+    def predict_id_mask(self, image: np.ndarray, conf: float = 0.9, out_hw: Optional[Tuple[int, int]] = None,
+                        suppress_small: bool = False, min_area: int = 100, imgsz: int = 640):
+        """The fused tail of `auto_segment` (reference yolo_seg/yolo_with_deva.py:51-86): predict(retina_masks=True,
+        conf) -> masks at the frame's size -> (bilinear to `out_hw` if it differs, :71-72) -> area test -> id paint.
+        -> (ids int64 [h,w] cuda, kept int32 [n] cpu (id per detection, 0 = suppressed), conf [n] cpu, cls [n] cpu)"""
+        if not self.seg:
+            raise ValueError("auto_segment needs a segmentation checkpoint")
+        imgs, _ = hostops.load_sources(image)
+        im = imgs[0]
+        oh, ow = im.shape[:2]
+        out_hw = (oh, ow) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
+        eng = self._engine()
+        dev = torch.device("cuda", self._dev_index)
+        boxed, _ = hostops.letterbox(im, imgsz)
+        H, W = boxed.shape[:2]
+        out = eng.forward(torch.from_numpy(boxed[None]).to(dev))
+        d = out["det"][0]
+        keep = d[:, 4] > conf
+        d = d[keep]
+        n = int(d.shape[0])
+        if n == 0:
+            z = torch.zeros(out_hw, dtype=torch.int64, device=dev)
+            e = torch.zeros(0)
+            return z, torch.zeros(0, dtype=torch.int32), e, e
+        boxes = hostops.scale_boxes_t((H, W), d[:, :4], (oh, ow))
+        cf = out["coeff"][0][keep]
+        if out_hw == (oh, ow):
+            _, ids, kept = eng.masks(0, cf, boxes, (oh, ow), retina=True, want_masks=False, want_ids=True,
+                                     suppress_small=suppress_small, min_area=min_area)
+        else:
+            # the reference resizes each float mask to (h,w) and thresholds at 0.5 (:71-79); do the same on the GPU tensors
+            m, _, _ = eng.masks(0, cf, boxes, (oh, ow), retina=True)
+            mf = torch.nn.functional.interpolate(m[None].float(), size=out_hw, mode="bilinear", align_corners=False,
+                                                 antialias=True)[0]
+            ids = torch.zeros(out_hw, dtype=torch.int64, device=dev)
+            kept = torch.zeros(n, dtype=torch.int32)
+            cur = 1
+            for i in range(n):
+                if suppress_small and float(mf[i].sum()) < min_area:
+                    continue
+                ids[mf[i] > 0.5] = cur
+                kept[i] = cur
+                cur += 1
+        return ids, kept.cpu(), d[:, 4].cpu(), d[:, 5].cpu()
