@@ -46,12 +46,25 @@ def parse():
     return ap.parse_args()
 
 
+def usable_cores() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota (a 1-GPU box gets a share
+    of a 256-thread host; oversubscribing torch's thread pool there is 20x slower than matching the share)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get("YOLOP_CPU_THREADS", "32"))))
+
+
 def cpu_baseline(variant: str, seg: bool, imgsz: int, frames: int):
     """The oracle (torch-CPU fp32 restatement of the reference's path; the reference's own `ultralytics` path
     cannot be installed) timed on this box's host cores on a bounded sample of the same workload."""
     from oracle.yolov10_oracle import Oracle
     from yolo_puncture_amd.weights import synthetic_state
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     st = synthetic_state(variant, 80, seg, seed=0)
     orc = Oracle(st, variant, 80, seg, "fp32")
@@ -68,7 +81,7 @@ def cpu_baseline(variant: str, seg: bool, imgsz: int, frames: int):
                 break
     return dict(value=round(frames * reps / dt, 2), unit="images/sec", cores=torch.get_num_threads(), kind="port",
                 sample=f"oracle fp32 (torch-CPU), YOLOv10-{variant.upper()} {imgsz}x{imgsz}, {frames} frames x {reps} passes, "
-                       f"one-to-one head only; host reports {cores} cpus")
+                       f"one-to-one head only; host reports {os.cpu_count()} cpus, {cores} usable")
 
 
 def main():

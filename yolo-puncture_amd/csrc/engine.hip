@@ -11,7 +11,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
+#include <fstream>
 #include <map>
+#include <sstream>
 #include <memory>
 
 using namespace yp;
@@ -564,6 +567,55 @@ static int autotune(yp_engine& e) {
     return YP_OK;
 }
 
+// Optional on-disk cache of the autotuner's choices (env YOLOP_TUNE_CACHE=<path prefix>): one file per
+// (variant, task, dtype, B, H, W), lines "<op name> <cfg>". Lets a profiled run skip the tuning launches.
+static std::string tune_cache_path(const yp_engine& e) {
+    const char* pre = std::getenv("YOLOP_TUNE_CACHE");
+    if (!pre || !*pre) return "";
+    std::ostringstream os;
+    os << pre << "_" << (char)e.desc.variant << (e.desc.task ? "seg" : "det") << "_nc" << e.desc.nc << "_dt" << e.dtype << "_" << e.pB << "x" << e.pH << "x" << e.pW << ".txt";
+    return os.str();
+}
+static bool load_tune_cache(yp_engine& e) {
+    const std::string path = tune_cache_path(e);
+    if (path.empty()) return false;
+    std::ifstream f(path);
+    if (!f) return false;
+    std::map<std::string, int> m;
+    std::string name;
+    int cfg;
+    while (f >> name >> cfg) m[name] = cfg;
+    for (Op& o : e.ops)
+        if (o.kind == OP_CONV || o.kind == OP_CONVT) {
+            auto it = m.find(o.name);
+            if (it == m.end()) return false;
+        }
+    for (Op& o : e.ops)
+        if (o.kind == OP_CONV || o.kind == OP_CONVT) {
+            o.cfg = m[o.name];
+            if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
+        }
+    return true;
+}
+static void save_tune_cache(const yp_engine& e) {
+    const std::string path = tune_cache_path(e);
+    if (path.empty()) return;
+    std::ofstream f(path);
+    for (const Op& o : e.ops)
+        if (o.kind == OP_CONV || o.kind == OP_CONVT) f << o.name << " " << o.cfg << "\n";
+}
+
+// the persistent conv kernels are additionally templated on <HAS_RES, OUT_F32>: make the reported symbol exact
+static void finish_kernel_names(yp_engine& e) {
+    for (Op& o : e.ops) {
+        if (o.kernel.find("_p_kernel<") == std::string::npos || o.kernel.find(",false>") != std::string::npos || o.kernel.find(",true>") != std::string::npos) continue;
+        const bool f32 = (o.kind == OP_CONV) && e.tensors[o.out.t].f32 && e.dtype == DT_BF16;
+        const bool res = o.res.t >= 0;
+        o.kernel.pop_back();
+        o.kernel += f32 ? ",false,true>" : (res ? ",true,false>" : ",false,false>");
+    }
+}
+
 static int run_all(yp_engine& e, const RunArgs& a, hipStream_t st) {
     for (const Op& o : e.ops) {
         hipError_t err = run_op(e, o, a, st);
@@ -851,11 +903,13 @@ static int prepare(yp_engine* e, int B, int H, int W, const uint8_t* in, float* 
     const bool fresh = !e->allocated;
     rc = allocate_plan(*e);
     if (rc != YP_OK) return rc;
-    if (fresh && e->tune) {
+    if (fresh && e->tune && !load_tune_cache(*e)) {
         HIPCHK(hipDeviceSynchronize());
         rc = autotune(*e);
         HIPCHK(hipDeviceSynchronize());
+        if (rc == YP_OK) save_tune_cache(*e);
     }
+    finish_kernel_names(*e);
     return rc;
 }
 
