@@ -365,6 +365,19 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
             p.Cout = o.out.C; p.M = B * e.tensors[o.in.t].H * e.tensors[o.in.t].W; p.Cin = o.in.C; p.ks = 1;
             p.Kpad = (o.in.C + 31) / 32 * 32; p.cfg = o.cfg;
             o.kernel = conv_kernel_name(p, e.dtype);
+        } else if (o.kind == OP_DWCONV) {
+            const char* t = e.dtype == DT_BF16 ? "bf16" : "f32";
+            char buf[64];
+            if (o.k == 3 && o.s == 1) snprintf(buf, sizeof(buf), "dwconv_row_kernel<%s,3,1,4>", t);
+            else if (o.k == 3 && o.s == 2) snprintf(buf, sizeof(buf), "dwconv_row_kernel<%s,3,2,2>", t);
+            else if (o.k == 7 && o.s == 1) snprintf(buf, sizeof(buf), "dwconv_row_kernel<%s,7,1,2>", t);
+            else snprintf(buf, sizeof(buf), "dwconv_kernel<%s>", t);
+            o.kernel = buf;
+        } else if (o.kind == OP_STEM) {
+            char buf[64];
+            if (e.dtype == DT_BF16) snprintf(buf, sizeof(buf), "stem_mfma_kernel<%d>", o.out.C / 16);
+            else snprintf(buf, sizeof(buf), "stem_kernel<f32>");
+            o.kernel = buf;
         } else o.kernel = kn[o.kind];
     }
     return YP_OK;
