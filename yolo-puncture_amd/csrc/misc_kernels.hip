@@ -121,18 +121,37 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
             const int ho = (int)((m / p.Wo) % p.Ho);
             const int b = (int)(m / ((long)p.Wo * p.Ho));
             const uint8_t* xb = p.x + (size_t)b * p.H * p.W * 3;
+            const int rowbytes = p.W * 3;                         // multiple of 4 (W is a multiple of 32)
+            const int sb = (wo * 2 - 1) * 3;                      // first byte of the 9-byte (3 px x BGR) segment; -3 at wo=0
+            const int ab = sb & ~3;                               // aligned dword holding it (floor, also for -3 -> -4)
+            const int sh = (sb - ab) * 8;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int hi = ho * 2 - 1 + ky;
                 const bool rok = (unsigned)hi < (unsigned)p.H;
+                const uint8_t* rp = xb + (size_t)(rok ? hi : 0) * rowbytes;
+                unsigned d[3];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {                      // three aligned dwords cover the 9 bytes; out-of-row dwords read as 0
+                    const int o = ab + 4 * k;
+                    const bool ok = rok && o >= 0 && o < rowbytes;
+                    d[k] = *(const unsigned*)(rp + (ok ? o : 0));
+                    d[k] = ok ? d[k] : 0u;
+                }
+                // 96-bit value >> sh : bytes 0..8
+                const unsigned long long lo = ((unsigned long long)d[1] << 32) | d[0];
+                const unsigned long long hi64 = ((unsigned long long)d[2] << 32) | d[1];
+                const unsigned long long b07 = sh ? ((lo >> sh) | ((unsigned long long)d[2] << (64 - sh))) : lo;   // bytes 0..7
+                const unsigned b8 = (unsigned)((hi64 >> sh) >> 32) & 0xffu;                                         // byte 8
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
                     const int wi = wo * 2 - 1 + kx;
-                    const bool ok = rok && ((unsigned)wi < (unsigned)p.W);
-                    const uint8_t* px = xb + ((size_t)(ok ? hi : 0) * p.W + (ok ? wi : 0)) * 3;
+                    const bool ok = (unsigned)wi < (unsigned)p.W;
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        const float v = ok ? ((float)px[c] / 255.0f) : 0.f;
+                        const int bi = kx * 3 + c;
+                        const unsigned byte = (bi < 8) ? (unsigned)((b07 >> (8 * bi)) & 0xffu) : b8;
+                        const float v = ok ? ((float)byte / 255.0f) : 0.f;
                         row[(ky * 3 + kx) * 3 + c] = (__bf16)v;
                     }
                 }
@@ -278,29 +297,32 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(const DwParams p) {
     const T* xb = (const T*)p.x + (size_t)b * p.H * p.W * p.x_stride + cin;
     const T* wb = (const T*)p.w + c;
     const int wi0 = wo0 * S - p.pad;
-#pragma unroll
+#pragma unroll(KS == 7 ? 1 : KS)
     for (int ky = 0; ky < KS; ++ky) {
+        // branch-free: clamp the coordinates (the clamped address is always inside the tensor) and zero the value
+        // afterwards, so that all loads of the row issue back to back instead of sitting behind exec-mask branches
         const int hi = ho * S - p.pad + ky;
-        if ((unsigned)hi >= (unsigned)p.H) continue;
+        const bool rok = (unsigned)hi < (unsigned)p.H;
+        const int hic = min(max(hi, 0), p.H - 1);
+        Vec8<T> xv[NCOL], wv[KS];
+#pragma unroll
+        for (int kx = 0; kx < KS; ++kx) wv[kx].load(wb + (size_t)(ky * KS + kx) * p.C);
+#pragma unroll
+        for (int col = 0; col < NCOL; ++col) {
+            const int wic = min(max(wi0 + col, 0), p.W - 1);
+            xv[col].load(xb + ((size_t)hic * p.W + wic) * p.x_stride);
+        }
         float wf[KS][8];
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            Vec8<T> wv;
-            wv.load(wb + (size_t)(ky * KS + kx) * p.C);
-            wv.unpack(wf[kx]);
-        }
+        for (int kx = 0; kx < KS; ++kx) wv[kx].unpack(wf[kx]);
 #pragma unroll
         for (int col = 0; col < NCOL; ++col) {
             const int wi = wi0 + col;
+            const float okf = (rok && (unsigned)wi < (unsigned)p.W) ? 1.0f : 0.0f;
             float xf[8];
-            if ((unsigned)wi < (unsigned)p.W) {
-                Vec8<T> xv;
-                xv.load(xb + ((size_t)hi * p.W + wi) * p.x_stride);
-                xv.unpack(xf);
-            } else {
+            xv[col].unpack(xf);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) xf[j] = 0.f;
-            }
+            for (int j = 0; j < 8; ++j) xf[j] *= okf;
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 const int kx = col - o * S;
