@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--seg", action="store_true", help="config 5: S-seg trunk + proto (mask tail not in the step)")
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-lanes", action="store_true", help="hipGraph without the concurrent head-branch lanes (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the bounded CPU-baseline sample")
@@ -127,6 +128,8 @@ def main():
                coeff=torch.empty((B, 300, 32), dtype=torch.float32, device=dev) if a.seg else None)
     gathered = torch.empty((world * B, 300, 6), dtype=torch.float32, device=dev) if world > 1 else None
     eng.set_graph(not a.no_graph)
+    if a.no_lanes and not a.no_graph:
+        eng._chk(eng.lib.yp_set_graph(eng._h, 2))
 
     def step():
         eng.forward(frames, out)

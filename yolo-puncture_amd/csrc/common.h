@@ -67,6 +67,7 @@ struct Op {
     double flops = 0, bytes = 0;  // algorithmic (filled by the plan)
     std::string kernel;           // device kernel symbol this op launches (filled by the plan)
     int cfg = -1;                 // autotuned conv_dma configuration (-1: heuristic)
+    int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
 };
 
 // ---------------------------------------------------------------------------------------------------------

@@ -58,6 +58,9 @@ struct yp_engine {
     hipStream_t own_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipGraphExec_t gexec = nullptr;
+    std::vector<hipStream_t> lane_streams;   // [0] unused (lane 0 = own_stream)
+    std::vector<hipEvent_t> lane_events;
+    bool use_lanes = true;
     struct Key { int B, H, W; const void* in; void* det; void* idx; void* coeff; } gkey{};
     int es() const { return dtype == DT_BF16 ? 2 : 4; }
 };
@@ -87,6 +90,7 @@ static int py_round(double x) {   // Python round(): half to even
 
 struct Builder {
     yp_engine& e;
+    int lane = 0;     // capture lane stamped on every op created from here on
     explicit Builder(yp_engine& en) : e(en) {}
 
     int tensor(const std::string& name, int C, int sdiv, bool f32 = false) {
@@ -110,6 +114,7 @@ struct Builder {
         Op o;
         o.kind = OP_CONV; o.name = name; o.in = in; o.out = out; o.res = res; o.k = k; o.s = s; o.act = act;
         o.widx = weight(name, out.C, in.C, k, 1);
+        o.lane = lane;
         e.ops.push_back(o);
     }
     void dwconv(const std::string& name, View in, View out, int k, int s, int act, View res = View{}, int gs = 0, int gstride = 0) {
@@ -117,6 +122,7 @@ struct Builder {
         o.kind = OP_DWCONV; o.name = name; o.in = in; o.out = out; o.res = res; o.k = k; o.s = s; o.act = act;
         o.gs = gs; o.gstride = gstride;
         o.widx = weight(name, out.C, 1, k, out.C);
+        o.lane = lane;
         e.ops.push_back(o);
     }
     int sdiv_of(View v) const { return e.tensors[v.t].sdiv; }
@@ -271,11 +277,13 @@ static int build_graph(yp_engine& e) {
         const View x = feat[l];
         const std::string pb = "model.23.one2one_cv2." + L, pc = "model.23.one2one_cv3." + L;
         const int b0 = B.tensor(pb + ".0", hc2, sd), b1 = B.tensor(pb + ".1", hc2, sd), b2 = B.tensor(pb + ".2", 64, sd, true);
+        B.lane = 1 + 3 * l;                                           // box branch of level l
         B.conv(pb + ".0", x, B.full(b0), 3, 1, ACT_SILU);
         B.conv(pb + ".1", B.full(b0), B.full(b1), 3, 1, ACT_SILU);
         B.conv(pb + ".2", B.full(b1), B.full(b2), 1, 1, ACT_NONE);
         const int k0 = B.tensor(pc + ".0.0", x.C, sd), k1 = B.tensor(pc + ".0.1", hc3, sd), k2 = B.tensor(pc + ".1.0", hc3, sd),
                   k3 = B.tensor(pc + ".1.1", hc3, sd), k4 = B.tensor(pc + ".2", nc, sd, true);
+        B.lane = 2 + 3 * l;                                           // class branch
         B.dwconv(pc + ".0.0", x, B.full(k0), 3, 1, ACT_SILU);
         B.conv(pc + ".0.1", B.full(k0), B.full(k1), 1, 1, ACT_SILU);
         B.dwconv(pc + ".1.0", B.full(k1), B.full(k2), 3, 1, ACT_SILU);
@@ -286,6 +294,7 @@ static int build_graph(yp_engine& e) {
         if (e.desc.task == YP_TASK_SEGMENT) {
             const std::string pm = "model.23.cv4." + L;
             const int m0 = B.tensor(pm + ".0", hc4, sd), m1 = B.tensor(pm + ".1", hc4, sd), m2 = B.tensor(pm + ".2", YP_NM, sd, true);
+            B.lane = 3 + 3 * l;                                       // mask-coefficient branch
             B.conv(pm + ".0", x, B.full(m0), 3, 1, ACT_SILU);
             B.conv(pm + ".1", B.full(m0), B.full(m1), 3, 1, ACT_SILU);
             B.conv(pm + ".2", B.full(m1), B.full(m2), 1, 1, ACT_NONE);
@@ -297,9 +306,11 @@ static int build_graph(yp_engine& e) {
         const std::string pp = "model.23.proto";
         const int p0 = B.tensor(pp + ".cv1", npr, 8), p1 = B.tensor(pp + ".upsample", npr, 4), p2 = B.tensor(pp + ".cv2", npr, 4),
                   p3 = B.tensor(pp + ".cv3", YP_NM, 4);
+        B.lane = 10;                                                  // prototype branch
         B.conv(pp + ".cv1", feat[0], B.full(p0), 3, 1, ACT_SILU);
         {
             Op o;
+            o.lane = B.lane;
             o.kind = OP_CONVT; o.name = pp + ".upsample"; o.in = B.full(p0); o.out = B.full(p1); o.k = 2; o.s = 2; o.act = ACT_NONE;
             o.widx = B.weight(pp + ".upsample", npr, npr, 2, 1, true);
             e.ops.push_back(o);
@@ -308,6 +319,8 @@ static int build_graph(yp_engine& e) {
         B.conv(pp + ".cv3", B.full(p2), B.full(p3), 1, 1, ACT_SILU);
         e.proto_t = p3;
     }
+    B.lane = 0;
+    head.lane = 0;
     e.ops.push_back(head);
     // the final 1x1 of each head branch emits fp32 logits
     return YP_OK;
@@ -629,6 +642,95 @@ static void finish_kernel_names(yp_engine& e) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Multi-lane launch for graph capture: ops carry a lane; every lane is a stream. Dependencies are derived from the
+// tensor views (RAW / WAR / WAW on overlapping channel ranges); a dependency that crosses lanes becomes an event
+// record on the producer's stream + a wait on the consumer's. Captured from lane 0's stream this yields a hipGraph
+// whose independent head branches (box / class / coefficient per level, prototypes) overlap with the rest of the neck.
+// ---------------------------------------------------------------------------------------------------------
+static bool views_overlap(const View& a, const View& b) {
+    return a.t >= 0 && a.t == b.t && a.coff < b.coff + b.C && b.coff < a.coff + a.C;
+}
+static void op_views(const Op& o, std::vector<View>& rd, std::vector<View>& wr) {
+    rd.clear(); wr.clear();
+    if (o.in.t >= 0) rd.push_back(o.in);
+    if (o.res.t >= 0) rd.push_back(o.res);
+    if (o.out.t >= 0) wr.push_back(o.out);
+    if (o.kind == OP_HEAD)
+        for (int l = 0; l < 3; ++l) {
+            if (o.box[l].t >= 0) rd.push_back(o.box[l]);
+            if (o.cls[l].t >= 0) rd.push_back(o.cls[l]);
+            if (o.cf[l].t >= 0) rd.push_back(o.cf[l]);
+        }
+}
+
+static int run_all_lanes(yp_engine& e, const RunArgs& a) {
+    const size_t n = e.ops.size();
+    int nl = 1;
+    for (const Op& o : e.ops) nl = std::max(nl, o.lane + 1);
+    while ((int)e.lane_streams.size() < nl) {
+        hipStream_t s;
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        e.lane_streams.push_back(s);
+    }
+    while (e.lane_events.size() < n + (size_t)nl) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e.lane_events.push_back(ev);
+    }
+    auto stream_of = [&](int lane) { return lane == 0 ? e.own_stream : e.lane_streams[lane]; };
+    std::vector<std::vector<View>> rds(n), wrs(n);
+    for (size_t i = 0; i < n; ++i) op_views(e.ops[i], rds[i], wrs[i]);
+    std::vector<char> recorded(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        const Op& o = e.ops[i];
+        // cross-lane dependencies: latest conflicting op of every other lane
+        std::vector<int> need(nl, -1);
+        for (size_t j = 0; j < i; ++j) {
+            const Op& q = e.ops[j];
+            if (q.lane == o.lane) continue;
+            bool dep = false;
+            for (const View& w : wrs[j]) {
+                for (const View& r : rds[i]) dep |= views_overlap(w, r);     // RAW
+                for (const View& w2 : wrs[i]) dep |= views_overlap(w, w2);   // WAW
+            }
+            for (const View& r : rds[j])
+                for (const View& w2 : wrs[i]) dep |= views_overlap(r, w2);   // WAR
+            if (dep) need[q.lane] = (int)j;
+        }
+        for (int l = 0; l < nl; ++l) {
+            if (need[l] < 0) continue;
+            const int j = need[l];
+            if (!recorded[j]) return fail(YP_ERR_STATE, "internal: dependency %s -> %s was not recorded", e.ops[j].name.c_str(), o.name.c_str());
+            HIPCHK(hipStreamWaitEvent(stream_of(o.lane), e.lane_events[j], 0));
+        }
+        hipError_t err = run_op(e, o, a, stream_of(o.lane));
+        if (err != hipSuccess) return fail(YP_ERR_HIP, "launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
+        // record after this op if a later op of another lane conflicts with it, or it is the last op of a side lane
+        bool later = false;
+        for (size_t k = i + 1; k < n && !later; ++k) {
+            const Op& q = e.ops[k];
+            if (q.lane == o.lane) continue;
+            for (const View& w : wrs[i]) {
+                for (const View& r : rds[k]) later |= views_overlap(w, r);
+                for (const View& w2 : wrs[k]) later |= views_overlap(w, w2);
+            }
+            for (const View& r : rds[i])
+                for (const View& w2 : wrs[k]) later |= views_overlap(r, w2);
+        }
+        if (later) {
+            HIPCHK(hipEventRecord(e.lane_events[i], stream_of(o.lane)));
+            recorded[i] = 1;
+        }
+    }
+    // join every side lane back into lane 0 (required to end the capture; harmless otherwise)
+    for (int l = 1; l < nl; ++l) {
+        HIPCHK(hipEventRecord(e.lane_events[n + l], e.lane_streams[l]));
+        HIPCHK(hipStreamWaitEvent(e.own_stream, e.lane_events[n + l], 0));
+    }
+    return YP_OK;
+}
+
 static int run_all(yp_engine& e, const RunArgs& a, hipStream_t st) {
     for (const Op& o : e.ops) {
         hipError_t err = run_op(e, o, a, st);
@@ -755,6 +857,8 @@ int yp_destroy(yp_engine* e) {
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    for (auto ls : e->lane_streams) (void)hipStreamDestroy(ls);
+    for (auto ev : e->lane_events) (void)hipEventDestroy(ev);
     delete e;
     return YP_OK;
 }
@@ -941,7 +1045,7 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
         if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
-        rc = run_all(*e, a, e->own_stream);
+        rc = e->use_lanes ? run_all_lanes(*e, a) : run_all(*e, a, e->own_stream);
         hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
         if (rc != YP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (ce != hipSuccess) return fail(YP_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
@@ -971,6 +1075,8 @@ int yp_set_autotune(yp_engine* e, int enable) {
 int yp_set_graph(yp_engine* e, int enable) {
     if (!e) return fail(YP_ERR_ARG, "null engine");
     e->use_graph = enable != 0;
+    e->use_lanes = enable != 2;          // 2 = graph without concurrent lanes (A/B measurements)
+    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
     return YP_OK;
 }
 

@@ -297,7 +297,8 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(const DwParams p) {
     const T* xb = (const T*)p.x + (size_t)b * p.H * p.W * p.x_stride + cin;
     const T* wb = (const T*)p.w + c;
     const int wi0 = wo0 * S - p.pad;
-#pragma unroll(KS == 7 ? 1 : KS)
+    constexpr int KY_UNROLL = (KS == 7) ? 1 : KS;      // 7x7: keep one kernel row of loads in flight (register budget)
+#pragma unroll KY_UNROLL
     for (int ky = 0; ky < KS; ++ky) {
         // branch-free: clamp the coordinates (the clamped address is always inside the tensor) and zero the value
         // afterwards, so that all loads of the row issue back to back instead of sitting behind exec-mask branches
