@@ -218,3 +218,20 @@ def test_topk_adversarial():
     # fewer anchors (84) than max_det: the remaining rows are zero / -1
     assert k == 84 and bool((out["idx"].cpu()[:, k:] == -1).all()) and float(out["det"].cpu()[:, k:].abs().max()) == 0.0
     eng.close()
+
+
+def test_graph_replay_matches_eager():
+    """hipGraph replay (with the concurrent head-branch lanes derived from tensor dependencies) must reproduce the
+    eager op-by-op result bit for bit, call after call."""
+    st, im = make_case("s", 80, True, 0, (3, 160, 192))
+    eng = _engine("s", 80, True, "bf16", st)
+    imc = im.cuda()
+    ref = {k: v.clone() for k, v in eng.forward(imc).items() if v is not None}
+    torch.cuda.synchronize()
+    eng.set_graph(True)
+    for _ in range(3):
+        out = eng.forward(imc)
+        torch.cuda.synchronize()
+        for k in ref:
+            assert torch.equal(out[k], ref[k]), k
+    eng.close()

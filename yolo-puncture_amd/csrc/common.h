@@ -19,6 +19,7 @@ enum OpKind {
     OP_ATTN = 5,      // PSA attention core: softmax(q^T k * scale) applied to v
     OP_HEAD = 6,      // DFL decode + sigmoid + two-stage top-k
     OP_CONVT = 7,     // ConvTranspose2d k2 s2 (Proto) = 4 strided 1x1 GEMMs
+    OP_POOL3 = 8,     // SPPF: three chained 5x5 max-pools in one launch (out = first pooled slice, 3*C channels written)
 };
 
 // Channel slice of an NHWC tensor: element (b,y,x,c) at ((b*H+y)*W+x)*pix_stride + coff + c
@@ -162,6 +163,7 @@ bool conv_dma_cfg_valid(const ConvParams& p, int cfg);
 hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st);
 hipError_t launch_pool5(const PoolParams& p, int dtype, hipStream_t st);
+hipError_t launch_sppf_pool3(const PoolParams& p, int dtype, hipStream_t st);
 hipError_t launch_upsample(const UpParams& p, int dtype, hipStream_t st);
 hipError_t launch_attention(const AttnParams& p, int dtype, hipStream_t st);
 hipError_t launch_head(const HeadParams& p, hipStream_t st);

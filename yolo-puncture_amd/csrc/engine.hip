@@ -161,10 +161,10 @@ struct Builder {
         const int c_ = in.C / 2, sd = sdiv_of(in);
         const int S = tensor(p + ".cat", 4 * c_, sd);
         conv(p + ".cv1", in, View{S, 0, c_}, 1, 1, ACT_SILU);
-        for (int i = 0; i < 3; ++i) {
-            Op o;
-            o.kind = OP_POOL5; o.name = p + ".m" + std::to_string(i);
-            o.in = View{S, i * c_, c_}; o.out = View{S, (i + 1) * c_, c_};
+        {
+            Op o;                                   // m(y), m(m(y)), m(m(m(y))) -> slices 1..3 of the concat buffer
+            o.kind = OP_POOL3; o.name = p + ".m";
+            o.in = View{S, 0, c_}; o.out = View{S, c_, 3 * c_};
             e.ops.push_back(o);
         }
         conv(p + ".cv2", full(S), out, 1, 1, ACT_SILU);
@@ -370,7 +370,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     }
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
     for (auto& o : e.ops) o.cfg = -1;
-    static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", ""};
+    static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel"};
     for (auto& o : e.ops) {
         if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
         else if (o.kind == OP_CONVT) {
@@ -497,6 +497,20 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff;
             p.B = B; p.H = ti.H; p.W = ti.W; p.C = o.in.C;
             return launch_pool5(p, e.dtype, st);
+        }
+        case OP_POOL3: {
+            const TensorDesc &ti = T(o.in), &to = T(o.out);
+            PoolParams p{};
+            p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff;
+            p.B = B; p.H = ti.H; p.W = ti.W; p.C = o.in.C;
+            if ((size_t)2 * ti.H * ti.W * 8 * e.es() <= 64 * 1024) return launch_sppf_pool3(p, e.dtype, st);
+            for (int i = 0; i < 3; ++i) {           // large maps: three chained launches
+                PoolParams q = p;
+                q.x_coff = o.in.coff + i * o.in.C; q.y_coff = o.out.coff + i * o.in.C;
+                hipError_t err = launch_pool5(q, e.dtype, st);
+                if (err != hipSuccess) return err;
+            }
+            return hipSuccess;
         }
         case OP_UPSAMPLE: {
             const TensorDesc &ti = T(o.in), &to = T(o.out);

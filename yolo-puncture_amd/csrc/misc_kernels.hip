@@ -426,6 +426,68 @@ hipError_t launch_pool5(const PoolParams& p, int dtype, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// SPPF: the three chained MaxPool2d(5,1,2) in ONE launch. A workgroup owns (image, 8-channel group): the H x W tile
+// lives in LDS as packed bf16x8 / f32x8 vectors and is pooled three times in place (two buffers), each result written
+// to its slice of the SPPF concat buffer. Max is exact in any precision, so this equals the chained reference bit for bit.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_pool3_kernel(const PoolParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
+    constexpr int VB = 8 * sizeof(T);
+    const int HW = p.H * p.W;
+    unsigned char* buf[2] = {plds, plds + (size_t)HW * VB};
+    const int groups = p.C >> 3;
+    const int g = blockIdx.x % groups, b = blockIdx.x / groups;
+    const T* xb = (const T*)p.x + (size_t)b * HW * p.x_stride + p.x_coff + g * 8;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+        Vec8<T> v;
+        v.load(xb + (size_t)i * p.x_stride);
+        *(Vec8<T>*)(buf[0] + (size_t)i * VB) = v;
+    }
+    __syncthreads();
+    for (int stage = 0; stage < 3; ++stage) {
+        const unsigned char* src = buf[stage & 1];
+        unsigned char* dst = buf[(stage + 1) & 1];
+        T* yb = (T*)p.y + (size_t)b * HW * p.y_stride + p.y_coff + stage * p.C + g * 8;
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const int y = i / p.W, x = i - y * p.W;
+            float m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = -INFINITY;
+            for (int dy = -2; dy <= 2; ++dy) {
+                const int yy = y + dy;
+                if ((unsigned)yy >= (unsigned)p.H) continue;
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int xx = x + dx;
+                    if ((unsigned)xx >= (unsigned)p.W) continue;
+                    const Vec8<T> v = *(const Vec8<T>*)(src + (size_t)(yy * p.W + xx) * VB);
+                    float f[8];
+                    v.unpack(f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m[j] = fmaxf(m[j], f[j]);
+                }
+            }
+            Vec8<T> o;
+            o.pack(m);
+            *(Vec8<T>*)(dst + (size_t)i * VB) = o;
+            o.store(yb + (size_t)i * p.y_stride);
+        }
+        __syncthreads();
+    }
+}
+
+// p.y/y_coff = first pooled slice; the three results go to consecutive C-channel slices
+hipError_t launch_sppf_pool3(const PoolParams& p, int dtype, hipStream_t st) {
+    const size_t es = dtype == DT_BF16 ? 2 : 4;
+    const size_t sh = (size_t)2 * p.H * p.W * 8 * es;
+    if (sh > 64 * 1024) return hipErrorInvalidValue;
+    const unsigned grid = (unsigned)(p.B * (p.C / 8));
+    if (dtype == DT_BF16) hipLaunchKernelGGL(sppf_pool3_kernel<__bf16>, dim3(grid), dim3(256), sh, st, p);
+    else hipLaunchKernelGGL(sppf_pool3_kernel<float>, dim3(grid), dim3(256), sh, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // nn.Upsample(scale_factor=2, mode="nearest") into a channel slice of the consumer's concat buffer
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
