@@ -25,7 +25,7 @@ template <int BK> __device__ __forceinline__ int swz_p(int row) {
     return BK == 32 ? (((row >> 2) & 1) << 1) : ((row >> 1) & 7);
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32>
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32, bool WRES>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvParams p, const int mtiles, const int ntiles, const int G) {
     constexpr int NW = WGM * WGN;
     constexpr int CPR = BK / 8;
@@ -34,8 +34,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
     constexpr int W_INSTR = BN * CPR / 64;
     constexpr int A_IPW = A_INSTR / NW;
     constexpr int W_IPW = (W_INSTR + NW - 1) / NW;
-    constexpr int LPW = A_IPW + W_IPW;
-    constexpr int SB = (BM + BN) * RB;
+    constexpr int LPW = A_IPW + (WRES ? 0 : W_IPW);   // WRES: the weight block is LDS-resident, only pixels stream
+    constexpr int SB = (WRES ? BM : (BM + BN)) * RB;
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
     constexpr int KSUB = BK / 32;
     constexpr int S = FM * FN;
@@ -69,6 +69,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
         const int co = n0 + wn * WN + a * 16 + fc * 4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias[a][r] = (co + r < p.Cout) ? p.bias[co + r] : 0.f;
+    }
+
+    // ---- WRES: the whole [BN][Kpad] weight block of this workgroup goes to LDS once, as nk tiles of [BN][BK] -------
+    unsigned char* const Wres = smem + NS * SB + 1024;
+    if (WRES) {
+        const int nkw = p.Kpad / BK;
+        const int ninstr = nkw * BN * CPR / 64;
+        for (int ii = wave; ii < ninstr; ii += NW) {
+            const int s = ii * 64 + lane;
+            const int rowg = s / CPR, pc = s - rowg * CPR;
+            const int kt = rowg / BN, n = rowg - kt * BN;
+            const int c = pc ^ swz_p<BK>(n);
+            const unsigned voff = (unsigned)(((n0 + n) * p.Kpad + kt * BK + c * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(Wres + ii * 1024), 16, voff, 0, 0, 0);
+        }
     }
 
     // ---- issue side -----------------------------------------------------------------------------------------
@@ -122,6 +137,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(sbase + (wave * A_IPW + j) * 1024), 16, voff, 0, 0, 0);
         }
         const bool live = it_tile < mtiles;
+        if (!WRES)
 #pragma unroll
         for (int j = 0; j < W_IPW; ++j) {
             const int ii = wave * W_IPW + j;
@@ -149,11 +165,15 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
     for (int ss = 0; ss < KSUB; ++ss) {
         const int ra = wm * WM + fr, rw = wn * WN + fr;
         aoff[ss] = ra * RB + (((ss * 4 + fc) ^ swz_p<BK>(ra)) * 16);
-        woff[ss] = BM * RB + rw * RB + (((ss * 4 + fc) ^ swz_p<BK>(rw)) * 16);
+        woff[ss] = (WRES ? 0 : BM * RB) + rw * RB + (((ss * 4 + fc) ^ swz_p<BK>(rw)) * 16);
     }
 
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue_next();
+    if (WRES) {                           // one-time drain: resident weights (and the first stages) have landed
+        wait_vmp<0>();
+        __builtin_amdgcn_s_barrier();
+    }
 
     int rslot = 0;
     unsigned epmask = 0;
@@ -176,11 +196,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
             issue_next();
             epmask <<= 1;
             const unsigned char* sb = smem + rslot * SB;
+            const unsigned char* wb_ = WRES ? (Wres + kt * BN * RB) : sb;
 #pragma unroll
             for (int ss = 0; ss < KSUB; ++ss) {
                 bf16x8 wf[FN], xf[FM];
 #pragma unroll
-                for (int a = 0; a < FN; ++a) wf[a] = *(const bf16x8*)(sb + woff[ss] + a * 16 * RB);
+                for (int a = 0; a < FN; ++a) wf[a] = *(const bf16x8*)(wb_ + woff[ss] + a * 16 * RB);
 #pragma unroll
                 for (int b = 0; b < FM; ++b) xf[b] = *(const bf16x8*)(sb + aoff[ss] + b * 16 * RB);
 #pragma unroll
@@ -245,7 +266,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct DmaPCfg { int BM, BN, NW, BK, NS; const char* name; };
+struct DmaPCfg { int BM, BN, NW, BK, NS; const char* name; int wres; };
 static const DmaPCfg kP[] = {
     {128, 32, 4, 32, 4, "conv_dma_p_kernel<128,32,4,1,32,4>"},     // 0
     {128, 64, 4, 32, 4, "conv_dma_p_kernel<128,64,2,2,32,4>"},     // 1
@@ -259,6 +280,16 @@ static const DmaPCfg kP[] = {
     {64, 128, 4, 64, 3, "conv_dma_p_kernel<64,128,2,2,64,3>"},     // 9
     {64, 64, 4, 64, 4, "conv_dma_p_kernel<64,64,2,2,64,4>"},       // 10
     {128, 64, 8, 64, 4, "conv_dma_p_kernel<128,64,4,2,64,4>"},     // 11
+    // weight-resident forms (ids 12..): the [BN][K] weight block stays in LDS, only the pixel tile streams
+    {128, 64, 4, 32, 4, "conv_dma_p_kernel<128,64,2,2,32,4,W>", 1},   // 12
+    {128, 64, 4, 64, 4, "conv_dma_p_kernel<128,64,2,2,64,4,W>", 1},   // 13
+    {64, 64, 4, 32, 4, "conv_dma_p_kernel<64,64,2,2,32,4,W>", 1},     // 14
+    {64, 64, 4, 64, 4, "conv_dma_p_kernel<64,64,2,2,64,4,W>", 1},     // 15
+    {128, 128, 4, 64, 3, "conv_dma_p_kernel<128,128,2,2,64,3,W>", 1}, // 16
+    {128, 128, 8, 64, 4, "conv_dma_p_kernel<128,128,4,2,64,4,W>", 1}, // 17
+    {128, 32, 4, 32, 4, "conv_dma_p_kernel<128,32,4,1,32,4,W>", 1},   // 18
+    {256, 64, 8, 64, 3, "conv_dma_p_kernel<256,64,4,2,64,3,W>", 1},   // 19
+    {128, 256, 8, 64, 3, "conv_dma_p_kernel<128,256,2,4,64,3,W>", 1}, // 20
 };
 constexpr int kNumP = (int)(sizeof(kP) / sizeof(kP[0]));
 int conv_dma_p_num_cfgs() { return kNumP; }
@@ -274,33 +305,37 @@ bool conv_dma_p_cfg_valid(const ConvParams& p, int c) {
     const int cpad = (p.Cout + 31) / 32 * 32;
     if (k.BN > 32 && k.BN >= 2 * cpad) return false;
     if (k.BN == 32 && p.Cout > 32) return false;
+    if (k.wres) {
+        const size_t sh = (size_t)k.NS * k.BM * k.BK * 2 + 1024 + (size_t)k.BN * p.Kpad * 2;
+        if (sh > 160 * 1024) return false;
+    }
     return true;
 }
 const char* conv_dma_p_kernel_name(int c) { return kP[c].name; }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32>
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32, bool WRES>
 static hipError_t launch_p_var(const ConvParams& p, hipStream_t st) {
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
-    const size_t sh = (size_t)NS * (BM + BN) * BK * 2 + 1024;
+    const size_t sh = WRES ? ((size_t)NS * BM * BK * 2 + 1024 + (size_t)BN * p.Kpad * 2) : ((size_t)NS * (BM + BN) * BK * 2 + 1024);
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(WGM * WGN == 8 ? 2 : 4, (160 * 1024) / sh));
     int G = (256 * per_cu) / ntiles;
     if (G < 1) G = 1;
     if (G > mtiles) G = mtiles;
-    auto kern = conv_dma_p_kernel<BM, BN, WGM, WGN, BK, NS, HAS_RES, OUT_F32>;
+    auto kern = conv_dma_p_kernel<BM, BN, WGM, WGN, BK, NS, HAS_RES, OUT_F32, WRES>;
     static bool attr = false;
-    if (!attr && sh > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    if (!attr && (WRES || sh > 64 * 1024)) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WRES ? 160 * 1024 : sh));
         if (e != hipSuccess) return e;
         attr = true;
     }
     hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3(WGM * WGN * 64), sh, st, p, mtiles, ntiles, G);
     return hipGetLastError();
 }
-template <int BM, int BN, int WGM, int WGN, int BK, int NS>
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool WRES = false>
 static hipError_t launch_p_one(const ConvParams& p, hipStream_t st) {
-    if (p.out_f32) return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, true>(p, st);
-    if (p.res) return launch_p_var<BM, BN, WGM, WGN, BK, NS, true, false>(p, st);
-    return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, false>(p, st);
+    if (p.out_f32) return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, true, WRES>(p, st);
+    if (p.res) return launch_p_var<BM, BN, WGM, WGN, BK, NS, true, false, WRES>(p, st);
+    return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, false, WRES>(p, st);
 }
 
 hipError_t launch_conv_dma_p(const ConvParams& p, int c, hipStream_t st) {
@@ -316,7 +351,16 @@ hipError_t launch_conv_dma_p(const ConvParams& p, int c, hipStream_t st) {
         case 8: return launch_p_one<128, 256, 2, 4, 32, 4>(p, st);
         case 9: return launch_p_one<64, 128, 2, 2, 64, 3>(p, st);
         case 10: return launch_p_one<64, 64, 2, 2, 64, 4>(p, st);
-        default: return launch_p_one<128, 64, 4, 2, 64, 4>(p, st);
+        case 11: return launch_p_one<128, 64, 4, 2, 64, 4>(p, st);
+        case 12: return launch_p_one<128, 64, 2, 2, 32, 4, true>(p, st);
+        case 13: return launch_p_one<128, 64, 2, 2, 64, 4, true>(p, st);
+        case 14: return launch_p_one<64, 64, 2, 2, 32, 4, true>(p, st);
+        case 15: return launch_p_one<64, 64, 2, 2, 64, 4, true>(p, st);
+        case 16: return launch_p_one<128, 128, 2, 2, 64, 3, true>(p, st);
+        case 17: return launch_p_one<128, 128, 4, 2, 64, 4, true>(p, st);
+        case 18: return launch_p_one<128, 32, 4, 1, 32, 4, true>(p, st);
+        case 19: return launch_p_one<256, 64, 4, 2, 64, 3, true>(p, st);
+        default: return launch_p_one<128, 256, 2, 4, 64, 3, true>(p, st);
     }
 }
 
