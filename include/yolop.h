@@ -114,6 +114,8 @@ int yp_set_autotune(yp_engine* e, int enable);
 
 /* Test hook: force conv tile configuration `cfg` wherever it is valid (-1 = off). Returns the number of configurations. */
 int yp_debug_force_conv_cfg(int cfg);
+/* Timing ablation for tools (results become wrong): 0 off, 1 conv kernels drop their stores, 2 drop their pixel loads. */
+int yp_debug_ablation(int v);
 
 /* Enable/disable hipGraph capture+replay of the forward (default on after the first eager run). */
 int yp_set_graph(yp_engine* e, int enable);

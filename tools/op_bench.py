@@ -10,6 +10,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--op", default="model.4.m.0.cv1"); ap.add_argument("--cfg", type=int, default=-1)
 ap.add_argument("--iters", type=int, default=20); ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--variant", default="s"); ap.add_argument("--imgsz", type=int, default=640)
+ap.add_argument("--ablate", type=int, default=0)
 ap.add_argument("--flush", default="", help="op to run before every timed run (evicts the caches), e.g. model.0")
 a = ap.parse_args()
 lib = load_library()
@@ -21,6 +22,7 @@ torch.cuda.synchronize()
 ops = eng.plan(a.batch, a.imgsz, a.imgsz)
 idx = [i for i, o in enumerate(ops) if o["name"] == a.op][0]
 lib.yp_debug_force_conv_cfg(a.cfg)
+lib.yp_debug_ablation(a.ablate)
 fidx = [i for i, o in enumerate(ops) if o["name"] == a.flush][0] if a.flush else -1
 for _ in range(3):
     eng.run_op(idx, im, out)

@@ -87,6 +87,7 @@ struct ConvParams {
     int up, oy, ox;                             // output pixel (ho,wo) -> (ho*up+oy, wo*up+ox) in an (Ho*up,Wo*up) image
     size_t x_bytes, w_bytes, y_bytes;           // extents of the x / packed-weight / y buffers (buffer descriptors)
     int cfg;                                    // conv_dma tile configuration (-1: heuristic)
+    int dbg;                                    // timing ablations (tests/tools only): 1 = drop stores, 2 = drop pixel loads
 };
 
 struct DwParams {
@@ -97,6 +98,7 @@ struct DwParams {
     const void* res; int res_stride, res_coff;
     int B, ks, stride, pad, act;
     int gs, gstride;
+    size_t x_bytes;            // extent of the x tensor (buffer descriptor of the row kernels)
 };
 
 struct StemParams {
@@ -144,6 +146,8 @@ const char* conv_dma_kernel_name(const ConvParams& p);
 int conv_dma_num_cfgs();
 void conv_dma_force_cfg(int cfg);
 int conv_dma_forced_cfg();
+void conv_set_debug_ablation(int v);
+int conv_debug_ablation();
 // halo-tiled 3x3 s1 kernel (conv_halo.hip); configuration ids are offset by 100 in ConvParams::cfg
 int conv_halo_num_cfgs();
 bool conv_halo_cfg_valid(const ConvParams& p, int c);

@@ -290,6 +290,9 @@ static int dma_heuristic(const ConvParams& p) {
 static int g_force_cfg = -1;   // debug/test override (yp_debug_force_conv_cfg)
 void conv_dma_force_cfg(int c) { g_force_cfg = c; }
 int conv_dma_forced_cfg() { return g_force_cfg; }
+static int g_dbg_ablate = 0;
+void conv_set_debug_ablation(int v) { g_dbg_ablate = v; }
+int conv_debug_ablation() { return g_dbg_ablate; }
 static int dma_choice(const ConvParams& p) {
     if (conv_dma_cfg_valid(p, g_force_cfg)) return g_force_cfg;
     return conv_dma_cfg_valid(p, p.cfg) ? p.cfg : dma_heuristic(p);

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
             const int c = pc ^ swz_p<BK>(row);
             const int m = mt * BM + row;
             unsigned mask = 0, base = 0;
-            if (mt < mtiles && m < p.M) {
+            if (mt < mtiles && m < p.M && p.dbg != 2) {
                 if (p.ks == 1) {
                     base = (unsigned)(m * p.x_stride + p.x_coff) * 2u;
                     mask = 1u;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
 #pragma unroll
         for (int a = 0; a < FN; ++a)
 #pragma unroll
-            for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};   // bias rides in the accumulator
 
         for (int kt = 0; kt < nk; ++kt) {
             {
@@ -236,11 +236,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
 #pragma unroll
                 for (int a = 0; a < FN; ++a) {
                     const int co = n0 + wn * WN + a * 16 + fc * 4;
-                    const bool ok = (m < p.M) && (co < p.Cout);
+                    const bool ok = (m < p.M) && (co < p.Cout) && (p.dbg != 1);
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float tt = acc[a][b][i] + bias[a][i];
+                        float tt = acc[a][b][i];
                         if (p.act == ACT_SILU) tt = silu_f2(tt);
                         v[i] = tt;
                     }

@@ -143,7 +143,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_p_kernel(const ConvP
 #pragma unroll
         for (int a = 0; a < FN; ++a)
 #pragma unroll
-            for (int r = 0; r < FM; ++r) acc[a][r] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < FM; ++r) acc[a][r] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};   // bias rides in the accumulator
 
         for (int c = 0; c < nchunk; ++c) {
             if (!first_iter) {
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_p_kernel(const ConvP
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        float tt = acc[a][r][i] + bias[a][i];
+                        float tt = acc[a][r][i];
                         if (p.act == ACT_SILU) tt = silu_fast(tt);
                         v[i] = tt;
                     }

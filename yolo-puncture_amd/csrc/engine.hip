@@ -444,7 +444,7 @@ static ConvParams conv_params(const yp_engine& e, const Op& o) {
     p.M = e.pB * to.H * to.W; p.ks = o.k; p.stride = o.s; p.pad = o.k / 2; p.act = o.act;
     p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
     p.up = 1; p.oy = 0; p.ox = 0;
-    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.y_bytes = to.bytes; p.cfg = o.cfg;
+    p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.y_bytes = to.bytes; p.cfg = o.cfg; p.dbg = conv_debug_ablation();
     return p;
 }
 
@@ -489,6 +489,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = to.H; p.Wo = to.W;
             if (o.res.t >= 0) { p.res = T(o.res).ptr; p.res_stride = T(o.res).C; p.res_coff = o.res.coff; }
             p.B = B; p.ks = o.k; p.stride = o.s; p.pad = o.k / 2; p.act = o.act; p.gs = o.gs; p.gstride = o.gstride;
+            p.x_bytes = ti.bytes;
             return launch_dwconv(p, e.dtype, st);
         }
         case OP_POOL5: {
@@ -1077,6 +1078,11 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     HIPCHK(hipEventRecord(e->ev_out, e->own_stream));
     HIPCHK(hipStreamWaitEvent(st, e->ev_out, 0));
     return YP_OK;
+}
+
+int yp_debug_ablation(int v) {
+    conv_set_debug_ablation(v);
+    return 0;
 }
 
 int yp_debug_force_conv_cfg(int cfg) {

@@ -12,6 +12,10 @@ template <typename T> struct Vec8;
 template <> struct Vec8<__bf16> {
     uint4 raw;
     __device__ inline void load(const __bf16* p) { raw = *(const uint4*)p; }
+    __device__ inline void load_buf(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        raw = make_uint4(v[0], v[1], v[2], v[3]);
+    }
     __device__ inline void store(__bf16* p) const { *(uint4*)p = raw; }
     __device__ inline void unpack(float* f) const {
         const uint32_t u[4] = {raw.x, raw.y, raw.z, raw.w};
@@ -31,6 +35,12 @@ template <> struct Vec8<__bf16> {
 template <> struct Vec8<float> {
     float4 a, b;
     __device__ inline void load(const float* p) { a = *(const float4*)p; b = *(const float4*)(p + 4); }
+    __device__ inline void load_buf(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+        const auto v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+        const auto v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, 0);
+        a = make_float4(__uint_as_float(v0[0]), __uint_as_float(v0[1]), __uint_as_float(v0[2]), __uint_as_float(v0[3]));
+        b = make_float4(__uint_as_float(v1[0]), __uint_as_float(v1[1]), __uint_as_float(v1[2]), __uint_as_float(v1[3]));
+    }
     __device__ inline void store(float* p) const { *(float4*)p = a; *(float4*)(p + 4) = b; }
     __device__ inline void unpack(float* f) const {
         f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
@@ -294,36 +304,34 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(const DwParams p) {
     for (int o = 0; o < NOUT; ++o)
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[o][j] = p.bias[c + j];
-    const T* xb = (const T*)p.x + (size_t)b * p.H * p.W * p.x_stride + cin;
     const T* wb = (const T*)p.w + c;
     const int wi0 = wo0 * S - p.pad;
+    // taps outside the image are read through a buffer descriptor with an out-of-range offset (hardware returns 0):
+    // no clamping, no masking arithmetic, and all loads of a kernel row issue back to back
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const unsigned xbase = (unsigned)(((size_t)b * p.H * p.W * p.x_stride + cin) * sizeof(T));
     constexpr int KY_UNROLL = (KS == 7) ? 1 : KS;      // 7x7: keep one kernel row of loads in flight (register budget)
 #pragma unroll KY_UNROLL
     for (int ky = 0; ky < KS; ++ky) {
-        // branch-free: clamp the coordinates (the clamped address is always inside the tensor) and zero the value
-        // afterwards, so that all loads of the row issue back to back instead of sitting behind exec-mask branches
         const int hi = ho * S - p.pad + ky;
         const bool rok = (unsigned)hi < (unsigned)p.H;
-        const int hic = min(max(hi, 0), p.H - 1);
         Vec8<T> xv[NCOL], wv[KS];
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) wv[kx].load(wb + (size_t)(ky * KS + kx) * p.C);
 #pragma unroll
         for (int col = 0; col < NCOL; ++col) {
-            const int wic = min(max(wi0 + col, 0), p.W - 1);
-            xv[col].load(xb + ((size_t)hic * p.W + wic) * p.x_stride);
+            const int wi = wi0 + col;
+            const bool ok = rok && ((unsigned)wi < (unsigned)p.W);
+            const unsigned off = ok ? xbase + (unsigned)((hi * p.W + wi) * p.x_stride) * (unsigned)sizeof(T) : 0x80000000u;
+            xv[col].load_buf(xrs, off);
         }
         float wf[KS][8];
 #pragma unroll
         for (int kx = 0; kx < KS; ++kx) wv[kx].unpack(wf[kx]);
 #pragma unroll
         for (int col = 0; col < NCOL; ++col) {
-            const int wi = wi0 + col;
-            const float okf = (rok && (unsigned)wi < (unsigned)p.W) ? 1.0f : 0.0f;
             float xf[8];
             xv[col].unpack(xf);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xf[j] *= okf;
 #pragma unroll
             for (int o = 0; o < NOUT; ++o) {
                 const int kx = col - o * S;
@@ -365,9 +373,10 @@ static void launch_dw_row(const DwParams& p, hipStream_t st) {
 
 template <typename T>
 static hipError_t launch_dwconv_t(const DwParams& p, hipStream_t st) {
-    if (p.ks == 3 && p.stride == 1) launch_dw_row<T, 3, 1, 4>(p, st);
-    else if (p.ks == 3 && p.stride == 2) launch_dw_row<T, 3, 2, 2>(p, st);
-    else if (p.ks == 7 && p.stride == 1) launch_dw_row<T, 7, 1, 2>(p, st);
+    const bool small = p.x_bytes < (1ull << 31);      // 32-bit buffer offsets
+    if (small && p.ks == 3 && p.stride == 1) launch_dw_row<T, 3, 1, 4>(p, st);
+    else if (small && p.ks == 3 && p.stride == 2) launch_dw_row<T, 3, 2, 2>(p, st);
+    else if (small && p.ks == 7 && p.stride == 1) launch_dw_row<T, 7, 1, 2>(p, st);
     else {
         const long total = (long)p.B * p.Ho * p.Wo * (p.C / 8);
         hipLaunchKernelGGL(dwconv_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, p);
