@@ -68,6 +68,9 @@ struct Op {
     double flops = 0, bytes = 0;  // algorithmic (filled by the plan)
     std::string kernel;           // device kernel symbol this op launches (filled by the plan)
     int cfg = -1;                 // autotuned conv_dma configuration (-1: heuristic)
+    int fuse_dw = -1;             // OP_CONV 1x1: index of the depthwise 3x3 op feeding it that can be fused in (graph pass)
+    bool fused = false;           // plan decision: this conv runs as the fused dw->pw kernel
+    bool skip = false;            // plan decision: this op's work is done by a fused consumer
     int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
 };
 
@@ -172,6 +175,16 @@ hipError_t launch_upsample(const UpParams& p, int dtype, hipStream_t st);
 hipError_t launch_attention(const AttnParams& p, int dtype, hipStream_t st);
 hipError_t launch_head(const HeadParams& p, hipStream_t st);
 size_t head_scratch_bytes(int B, int A);
+
+struct DwPwParams {                              // fused depthwise 3x3 s1 -> pointwise 1x1 (conv_dwpw.hip)
+    const void* x; int x_stride, x_coff; int B, H, W, C; size_t x_bytes;
+    const void* w_dw; const float* b_dw; int act_dw;            // depthwise: packed [9][C] bf16, bias fp32
+    const void* w_pw; int Kpad; size_t wpw_bytes; const float* b_pw; int act_pw;   // pointwise: packed [Cout^][Kpad]
+    void* y; int y_stride, y_coff; size_t y_bytes; int Cout; int out_f32;
+};
+bool conv_dwpw_valid(const DwPwParams& p);
+const char* conv_dwpw_kernel_name(const DwPwParams& p);
+hipError_t launch_conv_dwpw(const DwPwParams& p, hipStream_t st);
 
 struct MaskParams {
     const void* proto; int Hp, Wp;        // [Hp,Wp,32] engine dtype (one image)

@@ -1,0 +1,346 @@
+// Fused  depthwise 3x3 (s1, +bias, SiLU)  ->  pointwise 1x1 (+bias, SiLU)  in one persistent kernel (bf16).
+//
+// The depthwise result never goes to HBM: per 32-channel chunk the input tile (+1-pixel halo) arrives in LDS by LDS-DMA
+// (same ring / exact vmcnt accounting as conv_halo_p.hip), the depthwise stage (VALU, fp32 accumulate) writes its result
+// - rounded to bf16 exactly like the materialised tensor of the unfused graph - straight into the LDS tile that the MFMA
+// stage reads as its pixel operand, and the pointwise GEMM accumulates over the chunks. Both weight sets and the depthwise
+// bias are LDS-resident for the lifetime of the workgroup. The loop is skewed: phase g runs depthwise(g) and MFMA(g-1)
+// between the same pair of barriers, so the VALU-heavy stage of one wave overlaps the matrix stage of another.
+//
+// Used for the class branch of the v10Detect head (`one2one_cv3.{l}.{0,1}.{0,1}`) and the dw->pw pairs of CIB
+// (SURVEY.md Appendix A.2/A.4 [U]; run inside `.predict`, reference yolo_seg/app.py:91). Saves one launch and one
+// write + read of the intermediate tensor per pair.
+#include "common.h"
+
+namespace yp {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+__device__ __forceinline__ float silu_q(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+template <int N> __device__ __forceinline__ void wait_vmq() {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | (7 << 4) | (0xF << 8) | (((N >> 4) & 3) << 14));
+}
+__device__ __forceinline__ int qswz(int row) { return ((row >> 2) & 1) << 1; }
+__device__ __forceinline__ void unpack8(const uint4 r, float* f) {
+    const unsigned u[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(u[i] << 16); f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
+}
+
+// TH x 16 output pixels, BN output channels; 4 waves as 2(m) x 2(n)
+template <int TH, int BN, bool OUT_F32>
+__global__ __launch_bounds__(256) void conv_dwpw_kernel(const DwPwParams p, const int tiles_h, const int tiles_w, const int ntiles,
+                                                       const int G) {
+    constexpr int NW = 4, WGM = 2, WGN = 2;
+    constexpr int BM = TH * 16;
+    constexpr int HP = (TH + 2) * 18;
+    constexpr int H_INSTR = (HP * 4 + 63) / 64;
+    constexpr int LH = (H_INSTR + NW - 1) / NW;
+    constexpr int HB = H_INSTR * 1024;
+    constexpr int NSH = 3;
+    constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
+    constexpr int S = FM * FN;
+    constexpr int PPT = BM * 4 / 256;                 // pixels per thread per chunk in the depthwise stage (8 channels each)
+    constexpr unsigned OOB = 0x80000000u;
+    static_assert(LH + 2 * S < 64, "vmcnt immediate");
+
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int nchunk = p.C >> 5;
+    unsigned char* const Hs = smem;                                   // NSH halo slots
+    unsigned char* const As = Hs + NSH * HB;                          // 2 pixel-operand tiles [BM][32] bf16
+    unsigned char* const dump = As + 2 * BM * 64;                     // 1 KiB
+    unsigned char* const Wpw = dump + 1024;                           // [nchunk][BN][32] bf16
+    unsigned char* const Wdw = Wpw + (size_t)nchunk * BN * 64;        // [nchunk*9 rows][32] bf16, rounded up to whole KiB
+    const int wdw_instr = (nchunk * 9 + 15) / 16;
+    float* const Bdw = (float*)(Wdw + (size_t)wdw_instr * 1024);      // [C] fp32, rounded up to whole KiB
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WGM, wn = wave / WGM;
+    const int fr = lane & 15, fc = lane >> 4;
+
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, j = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+    }
+    const int nt = bid % ntiles, j0 = bid / ntiles;
+    const int n0 = nt * BN;
+    const int num_tiles = p.B * tiles_h * tiles_w;
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_pw, 0, (int)p.wpw_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t drs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w_dw, 0, (int)(9 * p.C * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)p.b_dw, 0, (int)(p.C * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
+
+    float bias[FN][4];
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        const int co = n0 + wn * WN + a * 16 + fc * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[a][r] = (co + r < p.Cout) ? p.b_pw[co + r] : 0.f;
+    }
+
+    // ---- resident operands -----------------------------------------------------------------------------------------------
+    {
+        const int ninstr = nchunk * BN / 16;                           // pointwise weights: row rg = chunk*BN + n
+        for (int ii = wave; ii < ninstr; ii += NW) {
+            const int s = ii * 64 + lane;
+            const int rg = s >> 2, pc = s & 3;
+            const int ch = rg / BN, n = rg - ch * BN;
+            const int c8 = pc ^ qswz(rg);
+            const unsigned voff = (unsigned)(((n0 + n) * p.Kpad + ch * 32 + c8 * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(Wpw + ii * 1024), 16, voff, 0, 0, 0);
+        }
+        for (int ii = wave; ii < wdw_instr; ii += NW) {                // depthwise weights: row = chunk*9 + tap <- [tap][C]
+            const int s = ii * 64 + lane;
+            const int row = s >> 2, c8 = s & 3;
+            const int ch = row / 9, tap = row - ch * 9;
+            const unsigned voff = (row < nchunk * 9) ? (unsigned)((tap * p.C + ch * 32 + c8 * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(drs, (lds_void*)(Wdw + ii * 1024), 16, voff, 0, 0, 0);
+        }
+        const int b_instr = (p.C * 4 + 1023) / 1024;
+        for (int ii = wave; ii < b_instr; ii += NW) {
+            const unsigned voff = (unsigned)(ii * 1024 + lane * 16);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_void*)((unsigned char*)Bdw + ii * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+
+    // ---- issue side: halo pieces ------------------------------------------------------------------------------------------
+    unsigned hconst[LH];
+    auto set_tile = [&](int tile) {
+        int t = tile;
+        const int tw = t % tiles_w; t /= tiles_w;
+        const int th = t % tiles_h;
+        const int b = t / tiles_h;
+        const int h0 = th * TH, w0 = tw * 16;
+#pragma unroll
+        for (int j = 0; j < LH; ++j) {
+            const int ii = wave * LH + j;
+            const int s = ii * 64 + lane;
+            const int hp = s >> 2, pc = s & 3;
+            const int c8 = pc ^ qswz(hp);
+            const int hy = hp / 18, hx = hp - hy * 18;
+            const int hi = h0 - 1 + hy, wi = w0 - 1 + hx;
+            const bool ok = (tile < num_tiles) && (ii < H_INSTR) && (hp < HP) && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
+            hconst[j] = ok ? (unsigned)((((b * p.H + hi) * p.W + wi) * p.x_stride + p.x_coff) * 2 + c8 * 16) : OOB;
+        }
+    };
+    int it_tile = j0, it_c = 0, it_slot = 0;
+    set_tile(it_tile);
+    auto issue_next = [&]() {
+        unsigned char* dst = Hs + it_slot * HB;
+        const unsigned coff = (unsigned)it_c * 64u;
+#pragma unroll
+        for (int j = 0; j < LH; ++j) {
+            const int ii = wave * LH + j;
+            const unsigned voff = (hconst[j] == OOB) ? OOB : hconst[j] + coff;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)((ii < H_INSTR) ? dst + ii * 1024 : dump), 16, voff, 0, 0, 0);
+        }
+        it_slot = (it_slot + 1 == NSH) ? 0 : it_slot + 1;
+        if (++it_c == nchunk) {
+            it_c = 0;
+            it_tile += G;
+            set_tile(it_tile);
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < NSH - 1; ++s) issue_next();
+    wait_vmq<0>();
+    __builtin_amdgcn_s_barrier();
+
+    // depthwise stage of one chunk: thread -> channel group g8 (8 ch) x PPT pixels, result (bf16) into the A tile
+    const int g8 = tid & 3, pix0 = tid >> 2;
+    auto dw_stage = [&](int c, int hslot, int aslot) {
+        const unsigned char* hsl = Hs + hslot * HB;
+        unsigned char* asl = As + aslot * BM * 64;
+        float wf[9][8], bf[8];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) unpack8(*(const uint4*)(Wdw + (c * 9 + t) * 64 + g8 * 16), wf[t]);
+        {
+            const float4 b0 = *(const float4*)(Bdw + c * 32 + g8 * 8), b1 = *(const float4*)(Bdw + c * 32 + g8 * 8 + 4);
+            bf[0] = b0.x; bf[1] = b0.y; bf[2] = b0.z; bf[3] = b0.w; bf[4] = b1.x; bf[5] = b1.y; bf[6] = b1.z; bf[7] = b1.w;
+        }
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const int px = pix0 + 64 * i;
+            const int r = px >> 4, cx = px & 15;
+            float acc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = bf[j];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int hp = (r + ky) * 18 + cx + kx;
+                    float xf[8];
+                    unpack8(*(const uint4*)(hsl + hp * 64 + ((g8 ^ qswz(hp)) * 16)), xf);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(xf[j], wf[ky * 3 + kx][j], acc[j]);
+                }
+            __attribute__((aligned(16))) __bf16 o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (__bf16)(p.act_dw == ACT_SILU ? silu_q(acc[j]) : acc[j]);
+            *(uint4*)(asl + px * 64 + ((g8 ^ qswz(px)) * 16)) = *(const uint4*)o;
+        }
+    };
+
+    f32x4 acc[FN][FM];
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};
+    };
+    auto mfma_stage = [&](int c, int aslot) {
+        const unsigned char* asl = As + aslot * BM * 64;
+        bf16x8 wf[FN], xf[FM];
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int rw = c * BN + wn * WN + a * 16 + fr;
+            wf[a] = *(const bf16x8*)(Wpw + rw * 64 + ((fc ^ qswz(rw)) * 16));
+        }
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            const int row = wm * WM + b * 16 + fr;
+            xf[b] = *(const bf16x8*)(asl + row * 64 + ((fc ^ qswz(row)) * 16));
+        }
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc[a][b], 0, 0, 0);
+    };
+    auto epilogue = [&](int tile) {
+        int t = tile;
+        const int tw = t % tiles_w; t /= tiles_w;
+        const int th = t % tiles_h;
+        const int b = t / tiles_h;
+        const int wo = tw * 16 + fr;
+#pragma unroll
+        for (int bb = 0; bb < FM; ++bb) {
+            const int ho = th * TH + wm * (WM / 16) + bb;
+            const bool pix_ok = (ho < p.H) && (wo < p.W);
+            const unsigned m = (unsigned)((b * p.H + ho) * p.W + wo);
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int co = n0 + wn * WN + a * 16 + fc * 4;
+                const bool ok = pix_ok && (co < p.Cout);
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = (p.act_pw == ACT_SILU) ? silu_q(acc[a][bb][i]) : acc[a][bb][i];
+                if (OUT_F32) {
+                    const unsigned off = ok ? (m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(v[0], v[1], v[2], v[3])), yrs, off, 0, 0);
+                } else {
+                    const unsigned off = ok ? (m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 2u : OOB;
+                    __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    __builtin_amdgcn_raw_buffer_store_b64(*(const __attribute__((ext_vector_type(2))) unsigned*)o, yrs, off, 0, 0);
+                }
+            }
+        }
+    };
+
+    // ---- skewed pipeline over the flattened (tile, chunk) sequence --------------------------------------------------------
+    int rd_slot = 0, g = 0;
+    unsigned epmask = 0;
+    bool first = true;
+    int prev_tile = -1, prev_c = 0;
+    reset_acc();
+    for (int tile = j0; tile < num_tiles; tile += G) {
+        for (int c = 0; c < nchunk; ++c, ++g) {
+            if (!first) {
+                const int k = __builtin_popcount(epmask & 3u);
+                if (k == 0) wait_vmq<LH>();
+                else if (k == 1) wait_vmq<LH + S>();
+                else wait_vmq<LH + 2 * S>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's A-tile writes of the previous phase are done
+                __builtin_amdgcn_s_barrier();
+            }
+            first = false;
+            issue_next();
+            epmask <<= 1;
+            dw_stage(c, rd_slot, g & 1);
+            if (prev_tile >= 0) {
+                mfma_stage(prev_c, (g - 1) & 1);
+                if (prev_c == nchunk - 1) {
+                    epilogue(prev_tile);
+                    reset_acc();
+                    epmask |= 1u;
+                }
+            }
+            prev_tile = tile;
+            prev_c = c;
+            rd_slot = (rd_slot + 1 == NSH) ? 0 : rd_slot + 1;
+        }
+    }
+    // drain: MFMA + epilogue of the last chunk
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (prev_tile >= 0) {
+        mfma_stage(prev_c, (g - 1) & 1);
+        epilogue(prev_tile);
+    }
+    wait_vmq<0>();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+static size_t dwpw_lds(int TH, int BN, int C) {
+    const int HP = (TH + 2) * 18, H_INSTR = (HP * 4 + 63) / 64;
+    const int nchunk = C / 32;
+    return (size_t)3 * H_INSTR * 1024 + (size_t)2 * TH * 16 * 64 + 1024 + (size_t)nchunk * BN * 64 +
+           (size_t)((nchunk * 9 + 15) / 16) * 1024 + (size_t)((C * 4 + 1023) / 1024) * 1024;
+}
+
+static int dwpw_bn(const DwPwParams& p) {          // widest output-channel block whose weights fit next to the rings
+    for (int bn : {128, 64}) {
+        if (bn > ((p.Cout + 63) / 64) * 64) continue;
+        if (dwpw_lds(8, bn, p.C) <= 150 * 1024) return bn;
+    }
+    return 0;
+}
+
+bool conv_dwpw_valid(const DwPwParams& p) {
+    if ((p.C % 32) != 0 || p.Kpad != p.C || (p.Cout & 3) || (p.y_stride & 3) || (p.y_coff & 3)) return false;
+    if (p.x_bytes >= (1ull << 31) || p.y_bytes >= (1ull << 31) || p.wpw_bytes >= (1ull << 31)) return false;
+    if ((long)((p.H + 7) / 8 * 8) * ((p.W + 15) / 16 * 16) * 2 > (long)p.H * p.W * 3) return false;
+    return dwpw_bn(p) != 0;
+}
+
+const char* conv_dwpw_kernel_name(const DwPwParams& p) {
+    const int bn = dwpw_bn(p);
+    if (p.out_f32) return bn == 128 ? "conv_dwpw_kernel<8,128,true>" : "conv_dwpw_kernel<8,64,true>";
+    return bn == 128 ? "conv_dwpw_kernel<8,128,false>" : "conv_dwpw_kernel<8,64,false>";
+}
+
+template <int BN, bool OUT_F32>
+static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t st) {
+    constexpr int TH = 8;
+    const size_t sh = dwpw_lds(TH, BN, p.C);
+    const int tiles_h = (p.H + TH - 1) / TH, tiles_w = (p.W + 15) / 16, ntiles = (p.Cout + BN - 1) / BN;
+    const int num_tiles = p.B * tiles_h * tiles_w;
+    int G = 256 / ntiles;
+    if (sh <= 80 * 1024) G *= 2;
+    if (G < 1) G = 1;
+    if (G > num_tiles) G = num_tiles;
+    auto kern = conv_dwpw_kernel<TH, BN, OUT_F32>;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3(256), sh, st, p, tiles_h, tiles_w, ntiles, G);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_dwpw(const DwPwParams& p, hipStream_t st) {
+    const int bn = dwpw_bn(p);
+    if (bn == 128) return p.out_f32 ? launch_dwpw_t<128, true>(p, st) : launch_dwpw_t<128, false>(p, st);
+    return p.out_f32 ? launch_dwpw_t<64, true>(p, st) : launch_dwpw_t<64, false>(p, st);
+}
+
+}  // namespace yp

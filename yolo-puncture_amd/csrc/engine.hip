@@ -54,6 +54,7 @@ struct yp_engine {
     size_t mask_ws_bytes = 0;
     // hipGraph replay
     bool use_graph = false;
+    bool fuse = true;             // dw->pw fusion (YOLOP_NO_FUSE=1 disables, for A/B)
     bool tune = true;             // plan-time autotuning of the conv tile configuration
     hipStream_t own_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -322,6 +323,22 @@ static int build_graph(yp_engine& e) {
     B.lane = 0;
     head.lane = 0;
     e.ops.push_back(head);
+    // ---- fusion pass: depthwise 3x3 (s1, SiLU) whose only consumer is the next op, a 1x1 conv ------------------------------
+    for (size_t i = 0; i + 1 < e.ops.size(); ++i) {
+        const Op& d = e.ops[i];
+        Op& c = e.ops[i + 1];
+        if (d.kind != OP_DWCONV || d.k != 3 || d.s != 1 || d.res.t >= 0 || d.gs != 0) continue;
+        if (c.kind != OP_CONV || c.k != 1 || c.s != 1 || c.res.t >= 0) continue;
+        if (c.in.t != d.out.t || c.in.coff != d.out.coff || c.in.C != d.out.C) continue;
+        bool other_reader = false;
+        for (size_t j = 0; j < e.ops.size(); ++j) {
+            if (j == i + 1) continue;
+            const Op& q = e.ops[j];
+            for (const View* v : {&q.in, &q.res})
+                if (v->t == d.out.t && v->coff < d.out.coff + d.out.C && d.out.coff < v->coff + v->C) other_reader = true;
+        }
+        if (!other_reader) c.fuse_dw = (int)i;
+    }
     // the final 1x1 of each head branch emits fp32 logits
     return YP_OK;
 }
@@ -330,6 +347,7 @@ static int build_graph(yp_engine& e) {
 // plan: resolve shapes for (B,H,W), compute algorithmic flops/bytes
 // ---------------------------------------------------------------------------------------------------------
 static ConvParams conv_params(const yp_engine& e, const Op& o);
+static DwPwParams dwpw_params(const yp_engine& e, const Op& c);
 static size_t tensor_elem_bytes(const yp_engine& e, const TensorDesc& t) { return (t.f32 || e.dtype == DT_F32) ? 4 : 2; }
 
 static int make_plan(yp_engine& e, int B, int H, int W) {
@@ -371,7 +389,12 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel"};
+    for (auto& o : e.ops) { o.fused = false; o.skip = false; }
     for (auto& o : e.ops) {
+        if (o.kind == OP_CONV && o.fuse_dw >= 0 && e.dtype == DT_BF16 && e.fuse) {
+            const DwPwParams q = dwpw_params(e, o);
+            if (conv_dwpw_valid(q)) { o.fused = true; e.ops[o.fuse_dw].skip = true; o.kernel = conv_dwpw_kernel_name(q); continue; }
+        }
         if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
         else if (o.kind == OP_CONVT) {
             ConvParams p{};
@@ -461,6 +484,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             return launch_stem(p, e.dtype, st);
         }
         case OP_CONV:
+            if (o.fused) return launch_conv_dwpw(dwpw_params(e, o), st);
             return launch_conv(conv_params(e, o), e.dtype, st);
         case OP_CONVT: {
             const WeightDesc& w = e.weights[o.widx];
@@ -555,6 +579,7 @@ static int autotune(yp_engine& e) {
     RunArgs none{nullptr, nullptr, nullptr, nullptr};
     for (Op& o : e.ops) {
         if (o.kind != OP_CONV && o.kind != OP_CONVT) continue;
+        if (o.fused) continue;
         ConvParams p{};
         if (o.kind == OP_CONV) p = conv_params(e, o);
         else { p.Cin = o.in.C; p.Cout = o.out.C; p.ks = 1; p.Kpad = e.weights[o.widx].Kpad; p.M = e.pB * e.tensors[o.in.t].H * e.tensors[o.in.t].W;
@@ -646,6 +671,19 @@ static void save_tune_cache(const yp_engine& e) {
         if (o.kind == OP_CONV || o.kind == OP_CONVT) f << o.name << " " << o.cfg << "\n";
 }
 
+static DwPwParams dwpw_params(const yp_engine& e, const Op& c) {
+    const Op& d = e.ops[c.fuse_dw];
+    const WeightDesc &wd = e.weights[d.widx], &wp = e.weights[c.widx];
+    const TensorDesc &ti = e.tensors[d.in.t], &to = e.tensors[c.out.t];
+    DwPwParams p{};
+    p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = d.in.coff; p.B = e.pB; p.H = ti.H; p.W = ti.W; p.C = d.in.C; p.x_bytes = ti.bytes;
+    p.w_dw = wd.d_w; p.b_dw = wd.d_b; p.act_dw = d.act;
+    p.w_pw = wp.d_w; p.Kpad = wp.Kpad; p.wpw_bytes = wp.mat_bytes; p.b_pw = wp.d_b; p.act_pw = c.act;
+    p.y = to.ptr; p.y_stride = to.C; p.y_coff = c.out.coff; p.y_bytes = to.bytes; p.Cout = c.out.C;
+    p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
+    return p;
+}
+
 // the persistent conv kernels are additionally templated on <HAS_RES, OUT_F32>: make the reported symbol exact
 static void finish_kernel_names(yp_engine& e) {
     for (Op& o : e.ops) {
@@ -670,9 +708,11 @@ static void finish_kernel_names(yp_engine& e) {
 static bool views_overlap(const View& a, const View& b) {
     return a.t >= 0 && a.t == b.t && a.coff < b.coff + b.C && b.coff < a.coff + a.C;
 }
-static void op_views(const Op& o, std::vector<View>& rd, std::vector<View>& wr) {
+static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std::vector<View>& wr) {
     rd.clear(); wr.clear();
-    if (o.in.t >= 0) rd.push_back(o.in);
+    if (o.skip) return;
+    if (o.fused) rd.push_back(e.ops[o.fuse_dw].in);
+    else if (o.in.t >= 0) rd.push_back(o.in);
     if (o.res.t >= 0) rd.push_back(o.res);
     if (o.out.t >= 0) wr.push_back(o.out);
     if (o.kind == OP_HEAD)
@@ -699,10 +739,11 @@ static int run_all_lanes(yp_engine& e, const RunArgs& a) {
     }
     auto stream_of = [&](int lane) { return lane == 0 ? e.own_stream : e.lane_streams[lane]; };
     std::vector<std::vector<View>> rds(n), wrs(n);
-    for (size_t i = 0; i < n; ++i) op_views(e.ops[i], rds[i], wrs[i]);
+    for (size_t i = 0; i < n; ++i) op_views(e, e.ops[i], rds[i], wrs[i]);
     std::vector<char> recorded(n, 0);
     for (size_t i = 0; i < n; ++i) {
         const Op& o = e.ops[i];
+        if (o.skip) continue;
         // cross-lane dependencies: latest conflicting op of every other lane
         std::vector<int> need(nl, -1);
         for (size_t j = 0; j < i; ++j) {
@@ -752,6 +793,7 @@ static int run_all_lanes(yp_engine& e, const RunArgs& a) {
 
 static int run_all(yp_engine& e, const RunArgs& a, hipStream_t st) {
     for (const Op& o : e.ops) {
+        if (o.skip) continue;
         hipError_t err = run_op(e, o, a, st);
         if (err != hipSuccess) return fail(YP_ERR_HIP, "launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
     }
@@ -855,6 +897,7 @@ int yp_create(const yp_model_desc* desc, int device, yp_engine** out) {
     if (desc->task != YP_TASK_DETECT && desc->task != YP_TASK_SEGMENT) return fail(YP_ERR_ARG, "bad task");
     std::unique_ptr<yp_engine> e(new yp_engine());
     e->desc = *desc; e->device = device; e->dtype = desc->dtype;
+    { const char* nf = std::getenv("YOLOP_NO_FUSE"); e->fuse = !(nf && *nf == '1'); }
     int rc = build_graph(*e);
     if (rc != YP_OK) return rc;
     for (const Op& o : e->ops)
@@ -1119,7 +1162,7 @@ int yp_profile(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     for (int it = 0; it < iters; ++it) {
         for (size_t i = 0; i < n; ++i) {
             HIPCHK(hipEventRecord(ev[2 * i], st));
-            hipError_t err = run_op(*e, e->ops[i], a, st);
+            hipError_t err = e->ops[i].skip ? hipSuccess : run_op(*e, e->ops[i], a, st);
             if (err != hipSuccess) return fail(YP_ERR_HIP, "op %s: %s", e->ops[i].name.c_str(), hipGetErrorString(err));
             HIPCHK(hipEventRecord(ev[2 * i + 1], st));
         }
