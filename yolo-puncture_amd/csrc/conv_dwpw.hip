@@ -1,7 +1,8 @@
 // Fused  depthwise 3x3 (s1, +bias, SiLU)  ->  pointwise 1x1 (+bias, SiLU)  in one persistent kernel (bf16).
 //
 // The depthwise result never goes to HBM: per 32-channel chunk the input tile (+1-pixel halo) arrives in LDS by LDS-DMA
-// (same ring / exact vmcnt accounting as conv_halo_p.hip), the depthwise stage (VALU, fp32 accumulate) writes its result
+// (same ring / exact vmcnt accounting as conv_halo_p.hip), the depthwise stage (MFMA with diagonal weight fragments,
+// fp32 accumulate - the VALU form was measured VALU-bound at the speed of the two unfused kernels) writes its result
 // - rounded to bf16 exactly like the materialised tensor of the unfused graph - straight into the LDS tile that the MFMA
 // stage reads as its pixel operand, and the pointwise GEMM accumulates over the chunks. Both weight sets and the depthwise
 // bias are LDS-resident for the lifetime of the workgroup. The loop is skewed: phase g runs depthwise(g) and MFMA(g-1)
@@ -24,17 +25,15 @@ template <int N> __device__ __forceinline__ void wait_vmq() {
     __builtin_amdgcn_s_waitcnt((N & 0xF) | (7 << 4) | (0xF << 8) | (((N >> 4) & 3) << 14));
 }
 __device__ __forceinline__ int qswz(int row) { return ((row >> 2) & 1) << 1; }
-__device__ __forceinline__ void unpack8(const uint4 r, float* f) {
-    const unsigned u[4] = {r.x, r.y, r.z, r.w};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { f[2 * i] = __uint_as_float(u[i] << 16); f[2 * i + 1] = __uint_as_float(u[i] & 0xffff0000u); }
-}
 
-// TH x 16 output pixels, BN output channels; 4 waves as 2(m) x 2(n)
-template <int TH, int BN, bool OUT_F32>
-__global__ __launch_bounds__(256) void conv_dwpw_kernel(const DwPwParams p, const int tiles_h, const int tiles_w, const int ntiles,
+// TH x 16 output pixels, BN output channels; NW waves as 2(m) x NW/2(n). NW = 8 puts two waves on every SIMD so that one
+// wave's VALU work (fragment build, SiLU) overlaps the other's MFMAs with a single set of resident weights per CU.
+template <int TH, int BN, bool OUT_F32, int NW>
+__global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, const int tiles_h, const int tiles_w, const int ntiles,
                                                        const int G) {
-    constexpr int NW = 4, WGM = 2, WGN = 2;
+    constexpr int WGM = 2, WGN = NW / 2;
+    constexpr int RPW = TH / NW;                      // depthwise output rows owned by one wave
+    static_assert(RPW * NW == TH && RPW >= 1, "rows per wave");
     constexpr int BM = TH * 16;
     constexpr int HP = (TH + 2) * 18;
     constexpr int H_INSTR = (HP * 4 + 63) / 64;
@@ -43,7 +42,6 @@ __global__ __launch_bounds__(256) void conv_dwpw_kernel(const DwPwParams p, cons
     constexpr int NSH = 3;
     constexpr int WM = BM / WGM, WN = BN / WGN, FM = WM / 16, FN = WN / 16;
     constexpr int S = FM * FN;
-    constexpr int PPT = BM * 4 / 256;                 // pixels per thread per chunk in the depthwise stage (8 channels each)
     constexpr unsigned OOB = 0x80000000u;
     static_assert(LH + 2 * S < 64, "vmcnt immediate");
 
@@ -153,39 +151,72 @@ __global__ __launch_bounds__(256) void conv_dwpw_kernel(const DwPwParams p, cons
     wait_vmq<0>();
     __builtin_amdgcn_s_barrier();
 
-    // depthwise stage of one chunk: thread -> channel group g8 (8 ch) x PPT pixels, result (bf16) into the A tile
-    const int g8 = tid & 3, pix0 = tid >> 2;
+    // Depthwise stage of one chunk ON THE MATRIX CORES: out[ch][px] = sum_taps Wdiag_tap[ch][k] * x[k][px+tap], where
+    // Wdiag_tap is the 16x32 fragment that holds w[tap][ch] on the diagonal k == ch (+16 for the upper half) and zeros
+    // elsewhere. Products with the zeros are exact zeros, accumulation is fp32: same numbers as the VALU form, but a
+    // 16 px x 32 ch x 1 tap update costs 2 MFMAs (32 cycles) instead of ~16 VALU ops per lane, and needs no bf16 unpacking.
+    // Wave w owns output rows 2w, 2w+1 of the 8-row tile; a lane of the result holds 4 consecutive channels of one pixel,
+    // which go (bias + SiLU + bf16) with one ds_write_b64 into the pixel-operand tile of the pointwise GEMM.
+    // per-lane constants of the diagonal fragments: row fr carries channel fr + 16h; lane group fc holds k = 8fc..8fc+7, so
+    // the lane has a non-zero entry only for h == fc>>1 and only when (fc&1) == fr>>3, at dword (fr&7)>>1, halfword fr&1 -
+    // the same halfword the channel occupies in its LDS dword, so a fragment register is  (LDS dword) & mask.
+    unsigned dmask[2][4];
+    {
+        const bool valid = (fc & 1) == (fr >> 3);
+        const unsigned hw = (fr & 1) ? 0xffff0000u : 0x0000ffffu;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dmask[h][q] = (valid && h == (fc >> 1) && q == ((fr & 7) >> 1)) ? hw : 0u;
+    }
+    const int dch = (fr + 16 * (fc >> 1)) & ~1;       // even channel of the LDS dword this lane reads
     auto dw_stage = [&](int c, int hslot, int aslot) {
         const unsigned char* hsl = Hs + hslot * HB;
         unsigned char* asl = As + aslot * BM * 64;
-        float wf[9][8], bf[8];
+        bf16x8 wd[9][2];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) unpack8(*(const uint4*)(Wdw + (c * 9 + t) * 64 + g8 * 16), wf[t]);
-        {
-            const float4 b0 = *(const float4*)(Bdw + c * 32 + g8 * 8), b1 = *(const float4*)(Bdw + c * 32 + g8 * 8 + 4);
-            bf[0] = b0.x; bf[1] = b0.y; bf[2] = b0.z; bf[3] = b0.w; bf[4] = b1.x; bf[5] = b1.y; bf[6] = b1.z; bf[7] = b1.w;
+        for (int t = 0; t < 9; ++t) {
+            const unsigned wbits = *(const unsigned*)(Wdw + (c * 9 + t) * 64 + dch * 2);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint4 v = make_uint4(wbits & dmask[h][0], wbits & dmask[h][1], wbits & dmask[h][2], wbits & dmask[h][3]);
+                wd[t][h] = *(const bf16x8*)&v;
+            }
+        }
+        f32x4 dacc[RPW][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float4 bb = *(const float4*)(Bdw + c * 32 + 16 * h + fc * 4);
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) dacc[r][h] = f32x4{bb.x, bb.y, bb.z, bb.w};
         }
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            const int px = pix0 + 64 * i;
-            const int r = px >> 4, cx = px & 15;
-            float acc[8];
+        for (int hy = 0; hy < RPW + 2; ++hy)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] = bf[j];
+            for (int kx = 0; kx < 3; ++kx) {
+                const int hp = (RPW * wave + hy) * 18 + kx + fr;
+                const bf16x8 xf = *(const bf16x8*)(hsl + hp * 64 + ((fc ^ qswz(hp)) * 16));
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int r = hy - ky;
+                    if (r >= 0 && r < RPW) {
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int hp = (r + ky) * 18 + cx + kx;
-                    float xf[8];
-                    unpack8(*(const uint4*)(hsl + hp * 64 + ((g8 ^ qswz(hp)) * 16)), xf);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = fmaf(xf[j], wf[ky * 3 + kx][j], acc[j]);
+                        for (int h = 0; h < 2; ++h)
+                            dacc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[ky * 3 + kx][h], xf, dacc[r][h], 0, 0, 0);
+                    }
                 }
-            __attribute__((aligned(16))) __bf16 o[8];
+            }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (__bf16)(p.act_dw == ACT_SILU ? silu_q(acc[j]) : acc[j]);
-            *(uint4*)(asl + px * 64 + ((g8 ^ qswz(px)) * 16)) = *(const uint4*)o;
+        for (int r = 0; r < RPW; ++r) {
+            const int px = (RPW * wave + r) * 16 + fr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                __attribute__((aligned(8))) __bf16 o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(p.act_dw == ACT_SILU ? silu_q(dacc[r][h][i]) : dacc[r][h][i]);
+                const int c8 = 2 * h + (fc >> 1);
+                *(uint2*)(asl + px * 64 + ((c8 ^ qswz(px)) * 16) + (fc & 1) * 8) = *(const uint2*)o;
+            }
         }
     };
 
@@ -312,28 +343,28 @@ bool conv_dwpw_valid(const DwPwParams& p) {
 
 const char* conv_dwpw_kernel_name(const DwPwParams& p) {
     const int bn = dwpw_bn(p);
-    if (p.out_f32) return bn == 128 ? "conv_dwpw_kernel<8,128,true>" : "conv_dwpw_kernel<8,64,true>";
-    return bn == 128 ? "conv_dwpw_kernel<8,128,false>" : "conv_dwpw_kernel<8,64,false>";
+    if (p.out_f32) return bn == 128 ? "conv_dwpw_kernel<8,128,true,8>" : "conv_dwpw_kernel<8,64,true,8>";
+    return bn == 128 ? "conv_dwpw_kernel<8,128,false,8>" : "conv_dwpw_kernel<8,64,false,8>";
 }
 
 template <int BN, bool OUT_F32>
 static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t st) {
-    constexpr int TH = 8;
+    constexpr int TH = 8, NW = 8;
     const size_t sh = dwpw_lds(TH, BN, p.C);
     const int tiles_h = (p.H + TH - 1) / TH, tiles_w = (p.W + 15) / 16, ntiles = (p.Cout + BN - 1) / BN;
     const int num_tiles = p.B * tiles_h * tiles_w;
     int G = 256 / ntiles;
-    if (sh <= 80 * 1024) G *= 2;
+    if (sh <= 80 * 1024 && NW == 4) G *= 2;
     if (G < 1) G = 1;
     if (G > num_tiles) G = num_tiles;
-    auto kern = conv_dwpw_kernel<TH, BN, OUT_F32>;
+    auto kern = conv_dwpw_kernel<TH, BN, OUT_F32, NW>;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3(256), sh, st, p, tiles_h, tiles_w, ntiles, G);
+    hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3(NW * 64), sh, st, p, tiles_h, tiles_w, ntiles, G);
     return hipGetLastError();
 }
 
