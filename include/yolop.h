@@ -116,6 +116,9 @@ int yp_set_autotune(yp_engine* e, int enable);
 int yp_debug_force_conv_cfg(int cfg);
 /* Timing ablation for tools (results become wrong): 0 off, 1 conv kernels drop their stores, 2 drop their pixel loads. */
 int yp_debug_ablation(int v);
+/* Profiling hook: 100 MHz timestamps of the phases of the top-k kernel (image 0's workgroup, last launch):
+   [0] start, [1] keys loaded, [2] stage-1 select done, [3] stage-2 candidates scanned, [4] stage-2 select done, [5] decoded. */
+int yp_debug_head_clocks(uint64_t* out8);
 
 /* Enable/disable hipGraph capture+replay of the forward (default on after the first eager run). */
 int yp_set_graph(yp_engine* e, int enable);

@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Print the phase breakdown of head_select_kernel (image 0's workgroup) for a bs-32 v10-S forward."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from yolo_puncture_amd.engine import Engine, load_library
+from yolo_puncture_amd.weights import synthetic_state
+lib = load_library()
+eng = Engine("s", 80, False, "bf16", 0, state=synthetic_state("s", 80, False))
+im = torch.randint(0, 256, (32, 640, 640, 3), dtype=torch.uint8).cuda()
+for _ in range(3):
+    eng.forward(im)
+torch.cuda.synchronize()
+buf = (C.c_uint64 * 8)()
+lib.yp_debug_head_clocks(buf)
+t = [int(x) for x in buf]
+names = ["load keys", "stage-1 select", "stage-2 scan", "stage-2 select", "decode"]
+for i, n in enumerate(names):
+    print(f"{n:16s} {(t[i + 1] - t[i]) / 100.0:8.2f} us")
+print(f"{'total':16s} {(t[5] - t[0]) / 100.0:8.2f} us")

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU-box call that regenerates everything under profiles/ for the current build:
+#   bench line, rocprofv3 kernel stats of the same command, FETCH_SIZE / WRITE_SIZE passes -> traffic json, per-op table.
+# Outputs land in gpurun_out/refresh/ ; copy what is to be judged into profiles/ afterwards.
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+O=$R/gpurun_out/refresh
+rm -rf $O; mkdir -p $O
+export YOLOP_TUNE_CACHE=$O/tune.cache
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench_warm.log 2>&1              # fills the tune cache so the profiled runs do not autotune
+echo "[refresh] tune cache ready"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline > $O/bench_prof.log 2>&1
+cp $(ls $O/stats/*/*_kernel_stats.csv | head -1) $O/kernel_stats.csv
+echo "[refresh] kernel stats done"
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/fetch.log 2>&1
+echo "[refresh] fetch pass done"
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --no-cpu-baseline --steps 3 --warmup 1 > $O/write.log 2>&1
+python3 $R/tools/traffic_from_pmc.py $O/fetch $O/write $O/traffic_latest.json
+cp $O/traffic_latest.json $R/profiles/traffic_latest.json
+rm -rf $O/stats $O/fetch $O/write
+echo "[refresh] traffic done"
+python3 $R/tools/profile_ops.py > $O/per_op_table.txt 2>&1
+python3 $R/bench.py > $O/bench.log 2>&1                   # final line, with the fresh traffic json in place
+tail -1 $O/bench.log > $O/bench.json
+cat $O/bench.json

@@ -171,10 +171,12 @@ hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st);
 hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st);
 hipError_t launch_pool5(const PoolParams& p, int dtype, hipStream_t st);
 hipError_t launch_sppf_pool3(const PoolParams& p, int dtype, hipStream_t st);
+bool sppf_pool3_fits(const PoolParams& p, int dtype);
 hipError_t launch_upsample(const UpParams& p, int dtype, hipStream_t st);
 hipError_t launch_attention(const AttnParams& p, int dtype, hipStream_t st);
 hipError_t launch_head(const HeadParams& p, hipStream_t st);
 size_t head_scratch_bytes(int B, int A);
+hipError_t head_read_clocks(unsigned long long* out8);
 
 struct DwPwParams {                              // fused depthwise 3x3 s1 -> pointwise 1x1 (conv_dwpw.hip)
     const void* x; int x_stride, x_coff; int B, H, W, C; size_t x_bytes;

@@ -414,7 +414,8 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
             if (e.dtype == DT_BF16) snprintf(buf, sizeof(buf), "stem_mfma_kernel<%d>", o.out.C / 16);
             else snprintf(buf, sizeof(buf), "stem_kernel<f32>");
             o.kernel = buf;
-        } else o.kernel = kn[o.kind];
+        } else if (o.kind == OP_POOL3 && e.dtype == DT_BF16 && (o.in.C & 31) == 0) o.kernel = "sppf_pool3_bf16_kernel";
+        else o.kernel = kn[o.kind];
     }
     return YP_OK;
 }
@@ -528,7 +529,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             PoolParams p{};
             p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff;
             p.B = B; p.H = ti.H; p.W = ti.W; p.C = o.in.C;
-            if ((size_t)2 * ti.H * ti.W * 8 * e.es() <= 64 * 1024) return launch_sppf_pool3(p, e.dtype, st);
+            if (sppf_pool3_fits(p, e.dtype)) return launch_sppf_pool3(p, e.dtype, st);
             for (int i = 0; i < 3; ++i) {           // large maps: three chained launches
                 PoolParams q = p;
                 q.x_coff = o.in.coff + i * o.in.C; q.y_coff = o.out.coff + i * o.in.C;
@@ -1120,6 +1121,13 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     HIPCHK(hipGraphLaunch(e->gexec, e->own_stream));
     HIPCHK(hipEventRecord(e->ev_out, e->own_stream));
     HIPCHK(hipStreamWaitEvent(st, e->ev_out, 0));
+    return YP_OK;
+}
+
+int yp_debug_head_clocks(uint64_t* out8) {
+    if (!out8) return fail(YP_ERR_ARG, "yp_debug_head_clocks: null output");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(head_read_clocks((unsigned long long*)out8));
     return YP_OK;
 }
 

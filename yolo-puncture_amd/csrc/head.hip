@@ -16,7 +16,12 @@ namespace yp {
 
 constexpr int HT = 1024;         // threads of the select kernel
 constexpr int CAP = 12288;       // LDS key capacity of the select kernel (96 KiB)
-constexpr int MAXK = 512;        // max top-k supported (sorted with a 512-key bitonic network)
+constexpr int MAXK = 512;        // max top-k supported (rank-sorted in one step)
+
+// phase timestamps (s_memrealtime, 100 MHz) of image 0's workgroup in the last launch: tools read them through
+// yp_debug_head_clocks to see where the select kernel's time goes
+__device__ unsigned long long g_head_clk[8];
+#define HEAD_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_head_clk[i] = wall_clock64(); } while (0)
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 __device__ __forceinline__ unsigned long long make_key(float score, unsigned flat) {
@@ -53,6 +58,36 @@ __global__ __launch_bounds__(256) void anchor_max_kernel(const HeadParams p, uns
     if (sub == 0 && item < total) mkey[item] = __float_as_uint(sigmoidf_(mx));
 }
 
+// nc % 4 == 0 form: a workgroup owns 64 consecutive anchors of one level of one image = 16*nc consecutive float4s, read
+// with full-width coalesced loads; per-float4 maxima go through LDS and one thread per anchor finishes the row.
+__global__ __launch_bounds__(256) void anchor_max4_kernel(const HeadParams p, unsigned* __restrict__ mkey, const int blocks_per_image,
+                                                          const int nb0, const int nb1) {
+    __shared__ float part[64 * 64];                    // [64 anchors][nc/4 <= 64]
+    const int b = blockIdx.x / blocks_per_image, blk = blockIdx.x - b * blocks_per_image;
+    const int A0 = p.hw[0][0] * p.hw[0][1], A1 = p.hw[1][0] * p.hw[1][1], A2 = p.hw[2][0] * p.hw[2][1];
+    int l, a0, HWl, abase;
+    if (blk < nb0) { l = 0; a0 = blk * 64; HWl = A0; abase = 0; }
+    else if (blk < nb0 + nb1) { l = 1; a0 = (blk - nb0) * 64; HWl = A1; abase = A0; }
+    else { l = 2; a0 = (blk - nb0 - nb1) * 64; HWl = A2; abase = A0 + A1; }
+    const int na = min(64, HWl - a0);
+    const int q = p.nc >> 2;                            // float4s per anchor
+    const float4* src = (const float4*)(p.cls[l] + ((size_t)b * HWl + a0) * p.nc);
+    const int n4 = na * q;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = src[i];
+        part[i] = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+    }
+    __syncthreads();
+    // 4 threads per anchor
+    const int a = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    float mx = -INFINITY;
+    if (a < na)
+        for (int j = sub; j < q; j += 4) mx = fmaxf(mx, part[a * q + j]);
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    if (a < na && sub == 0) mkey[(size_t)b * p.A + abase + a0 + a] = __float_as_uint(sigmoidf_(mx));
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LDS helpers of kernel 2 (all HT threads participate)
 // ---------------------------------------------------------------------------------------------------------------
@@ -63,11 +98,16 @@ struct SelectShared {
     unsigned count;
 };
 
-// keys[0..n) -> the k largest keys, sorted descending, in out[0..k) (out may alias nothing in keys). n >= k.
-__device__ void select_topk_sorted(const unsigned long long* keys, int n, int k, unsigned long long* out512, SelectShared& S) {
+// keys[0..n) -> the k largest keys, sorted descending, in out512[0..k) (zero keys behind them). n >= k; keys are unique.
+// Radix select from the top byte down; it stops as soon as the bin that holds the k-th key is wanted whole (then the
+// threshold is the smallest key with that prefix) - in practice after the score bytes. The <= 512 survivors are ordered
+// by rank counting (two threads per key, broadcast LDS reads) instead of a barrier-bound sorting network.
+__device__ void select_topk_sorted(const unsigned long long* keys, int n, int k, unsigned long long* out512, unsigned long long* tmp512,
+                                   SelectShared& S) {
     const int tid = threadIdx.x;
-    if (tid == 0) { S.prefix = 0ull; S.want = (unsigned)k; }
+    if (tid == 0) { S.prefix = 0ull; S.want = (unsigned)k; S.count = 0xFFFFFFFFu; }
     __syncthreads();
+    unsigned long long kth = 0ull;
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 56 - 8 * pass;
         if (tid < 256) S.hist[tid] = 0;
@@ -79,52 +119,50 @@ __device__ void select_topk_sorted(const unsigned long long* keys, int n, int k,
         }
         __syncthreads();
         if (tid < 64) {   // one wave: find the bin holding the want-th largest key among the keys that match the prefix
-            // lane owns bins 4*lane .. 4*lane+3 ; suffix sums from the top
             unsigned c0 = S.hist[4 * tid], c1 = S.hist[4 * tid + 1], c2 = S.hist[4 * tid + 2], c3 = S.hist[4 * tid + 3];
             unsigned mine = c0 + c1 + c2 + c3;
-            unsigned above = 0;   // keys in bins of higher lanes
             unsigned run = mine;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
                 const unsigned t = __shfl_down(run, o, 64);
                 if (tid + o < 64) run += t;
             }
-            above = run - mine;   // sum over lanes > tid
+            const unsigned above = run - mine;   // keys in bins of higher lanes
             const unsigned want = S.want;
-            // the target bin is in the unique lane with above < want <= above + mine
-            if (above < want && want <= above + mine) {
-                unsigned acc = above;
+            if (above < want && want <= above + mine) {      // the target bin is in this (unique) lane
+                unsigned acc = above, cb;
                 int bin;
-                if (want <= acc + c3) bin = 3;
-                else { acc += c3; if (want <= acc + c2) bin = 2; else { acc += c2; if (want <= acc + c1) bin = 1; else { acc += c1; bin = 0; } } }
+                if (want <= acc + c3) { bin = 3; cb = c3; }
+                else { acc += c3; if (want <= acc + c2) { bin = 2; cb = c2; } else { acc += c2; if (want <= acc + c1) { bin = 1; cb = c1; } else { acc += c1; bin = 0; cb = c0; } } }
                 S.prefix = (pre << 8) | (unsigned long long)(4 * tid + bin);
                 S.want = want - acc;
+                S.count = (want - acc == cb) ? (unsigned)shift : 0xFFFFFFFFu;   // whole bin wanted -> done
             }
         }
         __syncthreads();
+        if (S.count != 0xFFFFFFFFu) { kth = S.prefix << S.count; break; }
+        kth = S.prefix;
     }
-    const unsigned long long kth = S.prefix;   // exact k-th largest key (keys are unique)
+    __syncthreads();
     if (tid == 0) S.count = 0;
-    for (int i = tid; i < 512; i += HT) out512[i] = 0ull;
+    for (int i = tid; i < 512; i += HT) { out512[i] = 0ull; tmp512[i] = 0ull; }
     __syncthreads();
     for (int i = tid; i < n; i += HT) {
         const unsigned long long key = keys[i];
-        if (key >= kth) out512[atomicAdd(&S.count, 1u)] = key;   // exactly k of them
+        if (key >= kth) tmp512[atomicAdd(&S.count, 1u)] = key;   // exactly k of them
     }
     __syncthreads();
-    // bitonic sort 512 keys descending (256 compare-exchanges per stage)
-    for (int k2 = 2; k2 <= 512; k2 <<= 1) {
-        for (int j = k2 >> 1; j > 0; j >>= 1) {
-            if (tid < 256) {
-                const int i = ((tid & ~(j - 1)) << 1) | (tid & (j - 1));
-                const int ixj = i + j;
-                const unsigned long long a = out512[i], b = out512[ixj];
-                const bool desc = (i & k2) == 0;
-                if ((a < b) == desc) { out512[i] = b; out512[ixj] = a; }
-            }
-            __syncthreads();
-        }
+    {
+        const int i = tid >> 1, half = tid & 1;
+        const unsigned long long mykey = tmp512[i];
+        unsigned rank = 0;
+        const unsigned long long* q = tmp512 + half * 256;
+#pragma unroll 8
+        for (int j = 0; j < 256; ++j) rank += (q[j] > mykey) ? 1u : 0u;
+        rank += __shfl_xor(rank, 1, 64);
+        if (half == 0 && i < k) out512[rank] = mykey;
     }
+    __syncthreads();
 }
 
 __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, const unsigned* __restrict__ mkey) {
@@ -132,17 +170,21 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
     unsigned long long* keys = lds;                 // [CAP]
     unsigned long long* best = lds + CAP;           // [512] sorted result of the last select
     unsigned long long* carry = best + 512;         // [512] running best-k between stage-2 rounds
-    int* sel = (int*)(carry + 512);                 // [MAXK] stage-1 winners (anchor ids, rank order)
+    unsigned long long* tmp = carry + 512;          // [512] unsorted survivors of a select
+    int* sel = (int*)(tmp + 512);                   // [MAXK] stage-1 winners (anchor ids, rank order)
     __shared__ SelectShared S;
     __shared__ unsigned nfill;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int A = p.A, k = min(p.max_det, A);
     const Locate locate{p.hw[0][0] * p.hw[0][1], p.hw[1][0] * p.hw[1][1], p.hw[2][0] * p.hw[2][1]};
 
+    HEAD_STAMP(0);
     // ---- stage 1: top-k anchors by (max score desc, anchor asc) ---------------------------------------------------------
     for (int a = tid; a < A; a += HT) keys[a] = ((unsigned long long)mkey[(size_t)b * A + a] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
     __syncthreads();
-    select_topk_sorted(keys, A, k, best, S);
+    HEAD_STAMP(1);
+    select_topk_sorted(keys, A, k, best, tmp, S);
+    HEAD_STAMP(2);
     for (int r = tid; r < k; r += HT) sel[r] = (int)(0xFFFFFFFFu - (unsigned)(best[r] & 0xFFFFFFFFull));
     const unsigned thr_bits = (unsigned)(best[k - 1] >> 32);   // every selected anchor has a class with score >= this
     __syncthreads();
@@ -161,27 +203,45 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
             const int chunk = min(total - f0, CAP - (int)nfill);
             if (chunk <= 0) break;
             const int take = min(chunk, total - f0);
-            for (int i = tid; i < take; i += HT) {
-                const int f = f0 + i;
-                const int r = f / p.nc, c = f - r * p.nc;
-                int l, loc, HWl;
-                locate(sel[r], l, loc, HWl);
-                const float s = sigmoidf_(p.cls[l][((size_t)b * HWl + loc) * p.nc + c]);
-                if (__float_as_uint(s) >= thr_bits) keys[atomicAdd(&nfill, 1u)] = make_key(s, (unsigned)f);
+            constexpr int U = 24;                                  // independent gathers in flight per thread
+            for (int i0 = tid; i0 < take; i0 += U * HT) {
+                float lg[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * HT;
+                    lg[u] = -INFINITY;
+                    if (i < take) {
+                        const int f = f0 + i;
+                        const int r = f / p.nc, c = f - r * p.nc;
+                        int l, loc, HWl;
+                        locate(sel[r], l, loc, HWl);
+                        lg[u] = p.cls[l][((size_t)b * HWl + loc) * p.nc + c];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int i = i0 + u * HT;
+                    if (i < take) {
+                        const float s = sigmoidf_(lg[u]);
+                        if (__float_as_uint(s) >= thr_bits) keys[atomicAdd(&nfill, 1u)] = make_key(s, (unsigned)(f0 + i));
+                    }
+                }
             }
             __syncthreads();
             f0 += take;
             if ((int)nfill + 1 >= CAP) break;
         }
         done = f0;
+        HEAD_STAMP(3);
         const int n = (int)nfill;
         const int kk = min(k, n);
-        select_topk_sorted(keys, n, kk, best, S);
+        select_topk_sorted(keys, n, kk, best, tmp, S);
         for (int i = tid; i < kk; i += HT) carry[i] = best[i];
         have = kk;
         __syncthreads();
     }
 
+    HEAD_STAMP(4);
     // ---- winners: DFL decode (softmax expectation over 16 bins per side), dist2bbox (xyxy) * stride ----------------------
     for (int r = tid; r < p.max_det; r += HT) {
         float* d = p.det + ((size_t)b * p.max_det + r) * 6;
@@ -231,13 +291,16 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
             for (int j = 0; j < 32; ++j) p.coeff[((size_t)b * p.max_det + r) * 32 + j] = cf[j];
         }
     }
+    HEAD_STAMP(5);
 }
+
+hipError_t head_read_clocks(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_head_clk), 8 * sizeof(unsigned long long)); }
 
 size_t head_scratch_bytes(int B, int A) { return (size_t)B * A * sizeof(unsigned); }
 
 hipError_t launch_head(const HeadParams& p, hipStream_t st) {
     if (p.A > CAP || p.max_det > MAXK || p.scratch == nullptr) return hipErrorInvalidValue;
-    const size_t sh = (size_t)(CAP + 1024) * 8 + MAXK * 4;
+    const size_t sh = (size_t)(CAP + 1536) * 8 + MAXK * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)head_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -245,8 +308,14 @@ hipError_t launch_head(const HeadParams& p, hipStream_t st) {
         attr_set = true;
     }
     unsigned* mkey = (unsigned*)p.scratch;
-    const long items = (long)p.B * p.A * 16;
-    hipLaunchKernelGGL(anchor_max_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, mkey);
+    if ((p.nc & 3) == 0 && p.nc <= 256) {
+        const int nb0 = (p.hw[0][0] * p.hw[0][1] + 63) / 64, nb1 = (p.hw[1][0] * p.hw[1][1] + 63) / 64, nb2 = (p.hw[2][0] * p.hw[2][1] + 63) / 64;
+        const int bpi = nb0 + nb1 + nb2;
+        hipLaunchKernelGGL(anchor_max4_kernel, dim3((unsigned)(p.B * bpi)), dim3(256), 0, st, p, mkey, bpi, nb0, nb1);
+    } else {
+        const long items = (long)p.B * p.A * 16;
+        hipLaunchKernelGGL(anchor_max_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, mkey);
+    }
     hipLaunchKernelGGL(head_select_kernel, dim3(p.B), dim3(HT), sh, st, p, mkey);
     return hipGetLastError();
 }

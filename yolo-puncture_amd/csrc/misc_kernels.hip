@@ -485,11 +485,92 @@ __global__ __launch_bounds__(256) void sppf_pool3_kernel(const PoolParams p) {
     }
 }
 
+// bf16 fast form: 32 channels (four 16-B pieces) of one image per workgroup, separable 5x5 max (row pass, column pass),
+// values kept in LDS as order-preserving int16 keys (k = x ^ ((x >> 15) & 0x7fff), an involution) so that one
+// v_pk_max_i16 handles two channels; clamped neighbour indices replace the -inf padding (max ignores duplicates).
+typedef short short2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16x2_key(unsigned d) {
+    const unsigned s = (d >> 15) & 0x00010001u;
+    return d ^ ((s << 15) - s);
+}
+__device__ __forceinline__ uint4 key4(const uint4 v) { return make_uint4(bf16x2_key(v.x), bf16x2_key(v.y), bf16x2_key(v.z), bf16x2_key(v.w)); }
+__device__ __forceinline__ unsigned pkmax(unsigned a, unsigned b) {
+    const short2v r = __builtin_elementwise_max(__builtin_bit_cast(short2v, a), __builtin_bit_cast(short2v, b));
+    return __builtin_bit_cast(unsigned, r);
+}
+__device__ __forceinline__ uint4 pkmax4(const uint4 a, const uint4 b) {
+    return make_uint4(pkmax(a.x, b.x), pkmax(a.y, b.y), pkmax(a.z, b.z), pkmax(a.w, b.w));
+}
+
+__global__ __launch_bounds__(256) void sppf_pool3_bf16_kernel(const PoolParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char plds[];
+    const int HW = p.H * p.W, W = p.W, H = p.H;
+    unsigned char* const bufA = plds;
+    unsigned char* const bufB = plds + (size_t)HW * 64;
+    unsigned char* const tmp = plds + (size_t)HW * 128;
+    const int groups = p.C >> 5;
+    const int g = blockIdx.x % groups, b = blockIdx.x / groups;
+    const __bf16* xb = (const __bf16*)p.x + (size_t)b * HW * p.x_stride + p.x_coff + g * 32;
+    const int items = HW * 4;
+    for (int i = threadIdx.x; i < items; i += 256) {
+        const uint4 v = *(const uint4*)(xb + (size_t)(i >> 2) * p.x_stride + (i & 3) * 8);
+        *(uint4*)(bufA + i * 16) = key4(v);
+    }
+    __syncthreads();
+    for (int stage = 0; stage < 3; ++stage) {
+        const unsigned char* src = (stage & 1) ? bufB : bufA;
+        unsigned char* dst = (stage & 1) ? bufA : bufB;
+        for (int i = threadIdx.x; i < items; i += 256) {          // row pass
+            const int px = i >> 2, y = px / W, x = px - y * W;
+            const int x0 = max(x - 2, 0), x1 = max(x - 1, 0), x3 = min(x + 1, W - 1), x4 = min(x + 2, W - 1);
+            const unsigned char* row = src + (size_t)(y * W) * 64 + (i & 3) * 16;
+            uint4 m = *(const uint4*)(row + x * 64);
+            m = pkmax4(m, *(const uint4*)(row + x0 * 64));
+            m = pkmax4(m, *(const uint4*)(row + x1 * 64));
+            m = pkmax4(m, *(const uint4*)(row + x3 * 64));
+            m = pkmax4(m, *(const uint4*)(row + x4 * 64));
+            *(uint4*)(tmp + i * 16) = m;
+        }
+        __syncthreads();
+        __bf16* yb = (__bf16*)p.y + (size_t)b * HW * p.y_stride + p.y_coff + stage * p.C + g * 32;
+        for (int i = threadIdx.x; i < items; i += 256) {          // column pass + store
+            const int px = i >> 2, y = px / W, x = px - y * W;
+            const int y0 = max(y - 2, 0), y1 = max(y - 1, 0), y3 = min(y + 1, H - 1), y4 = min(y + 2, H - 1);
+            const unsigned char* col = tmp + (size_t)x * 64 + (i & 3) * 16;
+            uint4 m = *(const uint4*)(col + (size_t)(y * W) * 64);
+            m = pkmax4(m, *(const uint4*)(col + (size_t)(y0 * W) * 64));
+            m = pkmax4(m, *(const uint4*)(col + (size_t)(y1 * W) * 64));
+            m = pkmax4(m, *(const uint4*)(col + (size_t)(y3 * W) * 64));
+            m = pkmax4(m, *(const uint4*)(col + (size_t)(y4 * W) * 64));
+            *(uint4*)(dst + i * 16) = m;
+            *(uint4*)(yb + (size_t)px * p.y_stride + (i & 3) * 8) = key4(m);
+        }
+        __syncthreads();
+    }
+}
+
+bool sppf_pool3_fits(const PoolParams& p, int dtype) {
+    if (dtype == DT_BF16 && (p.C & 31) == 0 && (p.x_stride & 7) == 0 && (p.x_coff & 7) == 0 && (p.y_stride & 7) == 0 && (p.y_coff & 7) == 0)
+        return (size_t)p.H * p.W * 192 <= 128 * 1024;
+    return (size_t)2 * p.H * p.W * 8 * (dtype == DT_BF16 ? 2 : 4) <= 64 * 1024;
+}
+
 // p.y/y_coff = first pooled slice; the three results go to consecutive C-channel slices
 hipError_t launch_sppf_pool3(const PoolParams& p, int dtype, hipStream_t st) {
+    if (!sppf_pool3_fits(p, dtype)) return hipErrorInvalidValue;
+    if (dtype == DT_BF16 && (p.C & 31) == 0 && (p.x_stride & 7) == 0 && (p.x_coff & 7) == 0 && (p.y_stride & 7) == 0 && (p.y_coff & 7) == 0) {
+        const size_t sh = (size_t)p.H * p.W * 192;
+        static bool attr = false;
+        if (!attr) {
+            hipError_t e = hipFuncSetAttribute((const void*)sppf_pool3_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return e;
+            attr = true;
+        }
+        hipLaunchKernelGGL(sppf_pool3_bf16_kernel, dim3((unsigned)(p.B * (p.C / 32))), dim3(256), sh, st, p);
+        return hipGetLastError();
+    }
     const size_t es = dtype == DT_BF16 ? 2 : 4;
     const size_t sh = (size_t)2 * p.H * p.W * 8 * es;
-    if (sh > 64 * 1024) return hipErrorInvalidValue;
     const unsigned grid = (unsigned)(p.B * (p.C / 8));
     if (dtype == DT_BF16) hipLaunchKernelGGL(sppf_pool3_kernel<__bf16>, dim3(grid), dim3(256), sh, st, p);
     else hipLaunchKernelGGL(sppf_pool3_kernel<float>, dim3(grid), dim3(256), sh, st, p);
