@@ -172,6 +172,8 @@ hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st);
 hipError_t launch_pool5(const PoolParams& p, int dtype, hipStream_t st);
 hipError_t launch_sppf_pool3(const PoolParams& p, int dtype, hipStream_t st);
 bool sppf_pool3_fits(const PoolParams& p, int dtype);
+bool dwconv_mfma_valid(const DwParams& p, int dtype);
+hipError_t launch_dwconv_mfma(const DwParams& p, hipStream_t st);
 hipError_t launch_upsample(const UpParams& p, int dtype, hipStream_t st);
 hipError_t launch_attention(const AttnParams& p, int dtype, hipStream_t st);
 hipError_t launch_head(const HeadParams& p, hipStream_t st);

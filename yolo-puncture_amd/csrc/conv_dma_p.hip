@@ -8,6 +8,13 @@
 // nothing to store). Iteration g: wait(g) ; barrier ; issue(g+NS-1) ; compute(g) ; [stores if g ends a tile].
 // Ops younger than L(g) at wait(g): L(g+1..g+NS-2) plus the stores of every tile end among the previous NS-1 iterations
 // -> s_waitcnt vmcnt((NS-2)*LPW + k*S), k = 0..NS-1.
+//
+// PIPE form (software-pipelined fragments). PMC on the 128->128 3x3 @40x40 layer: 1650 cycles per k-step for 512 cycles
+// of MFMA - with one workgroup per CU every wave passes the barrier at the same time, so the LDS-read burst of a k-step
+// and its MFMA burst alternate instead of overlapping. PIPE keeps two sets of fragment registers: iteration g reads the
+// fragments of k-step g+1 (whose stage is waited for one iteration earlier) while the MFMAs of k-step g run from the
+// registers read in iteration g-1. Ops younger than L(g+1) at wait(g): L(g+2..g+NS-2) plus the stores of the tile ends
+// among the previous NS-2 iterations -> vmcnt((NS-3)*LPW + k*S).
 #include "common.h"
 
 namespace yp {
@@ -25,7 +32,7 @@ template <int BK> __device__ __forceinline__ int swz_p(int row) {
     return BK == 32 ? (((row >> 2) & 1) << 1) : ((row >> 1) & 7);
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32, bool WRES>
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32, bool WRES, bool PIPE>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvParams p, const int mtiles, const int ntiles, const int G) {
     constexpr int NW = WGM * WGN;
     constexpr int CPR = BK / 8;
@@ -41,6 +48,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
     constexpr int S = FM * FN;
     static_assert((NW == 4 || NW == 8) && A_INSTR % NW == 0 && A_IPW >= 1, "tile/wave layout");
     static_assert((NS - 2) * LPW + (NS - 1) * S < 64, "vmcnt immediate");
+    static_assert(!PIPE || NS >= 4, "the pipelined form gives up one stage of prefetch distance");
     constexpr unsigned OOB = 0x80000000u;
 
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -177,6 +185,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
 
     int rslot = 0;
     unsigned epmask = 0;
+    bf16x8 cw[KSUB][FN], cx[KSUB][FM];            // PIPE: fragments of the current k-step
+    auto load_frags = [&](int slot, int ktn, bf16x8 (&wf)[KSUB][FN], bf16x8 (&xf)[KSUB][FM]) {
+        const unsigned char* sb = smem + slot * SB;
+        const unsigned char* wb_ = WRES ? (Wres + ktn * BN * RB) : sb;
+#pragma unroll
+        for (int ss = 0; ss < KSUB; ++ss) {
+#pragma unroll
+            for (int a = 0; a < FN; ++a) wf[ss][a] = *(const bf16x8*)(wb_ + woff[ss] + a * 16 * RB);
+#pragma unroll
+            for (int b = 0; b < FM; ++b) xf[ss][b] = *(const bf16x8*)(sb + aoff[ss] + b * 16 * RB);
+        }
+    };
+    if (PIPE) {
+        if (!WRES) {
+            wait_vmp<(NS - 2) * LPW>();           // stage 0 landed
+            __builtin_amdgcn_s_barrier();
+        }
+        load_frags(0, 0, cw, cx);
+        rslot = 1;
+    }
     for (int tile = j0; tile < mtiles; tile += G) {
         f32x4 acc[FN][FM];
 #pragma unroll
@@ -184,6 +212,36 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
 #pragma unroll
             for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};   // bias rides in the accumulator
 
+        if (PIPE) {
+            for (int kt = 0; kt < nk; ++kt) {
+                {
+                    const int k = __builtin_popcount(epmask & ((1u << (NS - 2)) - 1u));
+                    if (k == 0) wait_vmp<(NS - 3) * LPW>();
+                    else if (k == 1) wait_vmp<(NS - 3) * LPW + S>();
+                    else wait_vmp<(NS - 3) * LPW + 2 * S>();
+                }
+                __builtin_amdgcn_s_barrier();
+                issue_next();
+                epmask <<= 1;
+                bf16x8 nw_[KSUB][FN], nx_[KSUB][FM];
+                load_frags(rslot, (kt + 1 == nk) ? 0 : kt + 1, nw_, nx_);
+#pragma unroll
+                for (int ss = 0; ss < KSUB; ++ss)
+#pragma unroll
+                    for (int a = 0; a < FN; ++a)
+#pragma unroll
+                        for (int b = 0; b < FM; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cw[ss][a], cx[ss][b], acc[a][b], 0, 0, 0);
+#pragma unroll
+                for (int ss = 0; ss < KSUB; ++ss) {
+#pragma unroll
+                    for (int a = 0; a < FN; ++a) cw[ss][a] = nw_[ss][a];
+#pragma unroll
+                    for (int b = 0; b < FM; ++b) cx[ss][b] = nx_[ss][b];
+                }
+                rslot = (rslot + 1 == NS) ? 0 : rslot + 1;
+            }
+        } else
         for (int kt = 0; kt < nk; ++kt) {
             {
                 const int k = __builtin_popcount(epmask & ((1u << (NS - 1)) - 1u));
@@ -266,7 +324,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct DmaPCfg { int BM, BN, NW, BK, NS; const char* name; int wres; };
+struct DmaPCfg { int BM, BN, NW, BK, NS; const char* name; int wres; int pipe; };
 static const DmaPCfg kP[] = {
     {128, 32, 4, 32, 4, "conv_dma_p_kernel<128,32,4,1,32,4>"},     // 0
     {128, 64, 4, 32, 4, "conv_dma_p_kernel<128,64,2,2,32,4>"},     // 1
@@ -290,6 +348,19 @@ static const DmaPCfg kP[] = {
     {128, 32, 4, 32, 4, "conv_dma_p_kernel<128,32,4,1,32,4,W>", 1},   // 18
     {256, 64, 8, 64, 3, "conv_dma_p_kernel<256,64,4,2,64,3,W>", 1},   // 19
     {128, 256, 8, 64, 3, "conv_dma_p_kernel<128,256,2,4,64,3,W>", 1}, // 20
+    // software-pipelined fragment forms (ids 21..)
+    {256, 128, 8, 32, 4, "conv_dma_p_kernel<256,128,4,2,32,4,P>", 0, 1},     // 21
+    {256, 64, 8, 32, 4, "conv_dma_p_kernel<256,64,4,2,32,4,P>", 0, 1},       // 22
+    {128, 256, 8, 32, 4, "conv_dma_p_kernel<128,256,2,4,32,4,P>", 0, 1},     // 23
+    {128, 128, 4, 32, 4, "conv_dma_p_kernel<128,128,2,2,32,4,P>", 0, 1},     // 24
+    {128, 64, 4, 32, 4, "conv_dma_p_kernel<128,64,2,2,32,4,P>", 0, 1},       // 25
+    {64, 64, 4, 32, 4, "conv_dma_p_kernel<64,64,2,2,32,4,P>", 0, 1},         // 26
+    {64, 64, 4, 64, 4, "conv_dma_p_kernel<64,64,2,2,64,4,P>", 0, 1},         // 27
+    {128, 64, 8, 64, 4, "conv_dma_p_kernel<128,64,4,2,64,4,P>", 0, 1},       // 28
+    {128, 128, 8, 64, 4, "conv_dma_p_kernel<128,128,4,2,64,4,W,P>", 1, 1},   // 29
+    {64, 64, 4, 64, 4, "conv_dma_p_kernel<64,64,2,2,64,4,W,P>", 1, 1},       // 30
+    {128, 64, 4, 64, 4, "conv_dma_p_kernel<128,64,2,2,64,4,W,P>", 1, 1},     // 31
+    {128, 128, 8, 64, 4, "conv_dma_p_kernel<128,128,4,2,64,4,P>", 0, 1},     // 32
 };
 constexpr int kNumP = (int)(sizeof(kP) / sizeof(kP[0]));
 int conv_dma_p_num_cfgs() { return kNumP; }
@@ -313,7 +384,7 @@ bool conv_dma_p_cfg_valid(const ConvParams& p, int c) {
 }
 const char* conv_dma_p_kernel_name(int c) { return kP[c].name; }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32, bool WRES>
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32, bool WRES, bool PIPE>
 static hipError_t launch_p_var(const ConvParams& p, hipStream_t st) {
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
     const size_t sh = WRES ? ((size_t)NS * BM * BK * 2 + 1024 + (size_t)BN * p.Kpad * 2) : ((size_t)NS * (BM + BN) * BK * 2 + 1024);
@@ -321,7 +392,7 @@ static hipError_t launch_p_var(const ConvParams& p, hipStream_t st) {
     int G = (256 * per_cu) / ntiles;
     if (G < 1) G = 1;
     if (G > mtiles) G = mtiles;
-    auto kern = conv_dma_p_kernel<BM, BN, WGM, WGN, BK, NS, HAS_RES, OUT_F32, WRES>;
+    auto kern = conv_dma_p_kernel<BM, BN, WGM, WGN, BK, NS, HAS_RES, OUT_F32, WRES, PIPE>;
     static bool attr = false;
     if (!attr && (WRES || sh > 64 * 1024)) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WRES ? 160 * 1024 : sh));
@@ -331,11 +402,11 @@ static hipError_t launch_p_var(const ConvParams& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3(WGM * WGN * 64), sh, st, p, mtiles, ntiles, G);
     return hipGetLastError();
 }
-template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool WRES = false>
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool WRES = false, bool PIPE = false>
 static hipError_t launch_p_one(const ConvParams& p, hipStream_t st) {
-    if (p.out_f32) return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, true, WRES>(p, st);
-    if (p.res) return launch_p_var<BM, BN, WGM, WGN, BK, NS, true, false, WRES>(p, st);
-    return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, false, WRES>(p, st);
+    if (p.out_f32) return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, true, WRES, PIPE>(p, st);
+    if (p.res) return launch_p_var<BM, BN, WGM, WGN, BK, NS, true, false, WRES, PIPE>(p, st);
+    return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, false, WRES, PIPE>(p, st);
 }
 
 hipError_t launch_conv_dma_p(const ConvParams& p, int c, hipStream_t st) {
@@ -360,7 +431,19 @@ hipError_t launch_conv_dma_p(const ConvParams& p, int c, hipStream_t st) {
         case 17: return launch_p_one<128, 128, 4, 2, 64, 4, true>(p, st);
         case 18: return launch_p_one<128, 32, 4, 1, 32, 4, true>(p, st);
         case 19: return launch_p_one<256, 64, 4, 2, 64, 3, true>(p, st);
-        default: return launch_p_one<128, 256, 2, 4, 64, 3, true>(p, st);
+        case 20: return launch_p_one<128, 256, 2, 4, 64, 3, true>(p, st);
+        case 21: return launch_p_one<256, 128, 4, 2, 32, 4, false, true>(p, st);
+        case 22: return launch_p_one<256, 64, 4, 2, 32, 4, false, true>(p, st);
+        case 23: return launch_p_one<128, 256, 2, 4, 32, 4, false, true>(p, st);
+        case 24: return launch_p_one<128, 128, 2, 2, 32, 4, false, true>(p, st);
+        case 25: return launch_p_one<128, 64, 2, 2, 32, 4, false, true>(p, st);
+        case 26: return launch_p_one<64, 64, 2, 2, 32, 4, false, true>(p, st);
+        case 27: return launch_p_one<64, 64, 2, 2, 64, 4, false, true>(p, st);
+        case 28: return launch_p_one<128, 64, 4, 2, 64, 4, false, true>(p, st);
+        case 29: return launch_p_one<128, 128, 4, 2, 64, 4, true, true>(p, st);
+        case 30: return launch_p_one<64, 64, 2, 2, 64, 4, true, true>(p, st);
+        case 31: return launch_p_one<128, 64, 2, 2, 64, 4, true, true>(p, st);
+        default: return launch_p_one<128, 128, 4, 2, 64, 4, false, true>(p, st);
     }
 }
 

@@ -404,7 +404,13 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         } else if (o.kind == OP_DWCONV) {
             const char* t = e.dtype == DT_BF16 ? "bf16" : "f32";
             char buf[64];
-            if (o.k == 3 && o.s == 1) snprintf(buf, sizeof(buf), "dwconv_row_kernel<%s,3,1,4>", t);
+            DwParams q{};
+            q.H = q.Ho = e.tensors[o.in.t].H; q.W = q.Wo = e.tensors[o.in.t].W; q.C = o.out.C; q.ks = o.k; q.stride = o.s; q.gs = o.gs;
+            q.x_stride = e.tensors[o.in.t].C; q.x_coff = o.in.coff; q.y_stride = e.tensors[o.out.t].C; q.y_coff = o.out.coff;
+            q.res = o.res.t >= 0 ? (const void*)1 : nullptr;
+            q.x_bytes = (size_t)B * q.H * q.W * q.x_stride * 2;
+            if (dwconv_mfma_valid(q, e.dtype)) snprintf(buf, sizeof(buf), "dwconv_mfma_kernel<%d>", o.k);
+            else if (o.k == 3 && o.s == 1) snprintf(buf, sizeof(buf), "dwconv_row_kernel<%s,3,1,4>", t);
             else if (o.k == 3 && o.s == 2) snprintf(buf, sizeof(buf), "dwconv_row_kernel<%s,3,2,2>", t);
             else if (o.k == 7 && o.s == 1) snprintf(buf, sizeof(buf), "dwconv_row_kernel<%s,7,1,2>", t);
             else snprintf(buf, sizeof(buf), "dwconv_kernel<%s>", t);
@@ -691,11 +697,12 @@ static void finish_kernel_names(yp_engine& e) {
         if (o.kernel.find("_p_kernel<") == std::string::npos || o.kernel.find(",false>") != std::string::npos || o.kernel.find(",true>") != std::string::npos) continue;
         const bool f32 = (o.kind == OP_CONV) && e.tensors[o.out.t].f32 && e.dtype == DT_BF16;
         const bool res = o.res.t >= 0;
-        bool wres = false;
+        bool wres = false, pipe = false;
+        if (o.kernel.size() > 3 && o.kernel.compare(o.kernel.size() - 3, 3, ",P>") == 0) { pipe = true; o.kernel.erase(o.kernel.size() - 3); o.kernel += ">"; }
         if (o.kernel.size() > 3 && o.kernel.compare(o.kernel.size() - 3, 3, ",W>") == 0) { wres = true; o.kernel.erase(o.kernel.size() - 3); }
         else o.kernel.pop_back();
         o.kernel += f32 ? ",false,true" : (res ? ",true,false" : ",false,false");
-        if (o.kernel.find("conv_dma_p_kernel") != std::string::npos) o.kernel += wres ? ",true" : ",false";
+        if (o.kernel.find("conv_dma_p_kernel") != std::string::npos) { o.kernel += wres ? ",true" : ",false"; o.kernel += pipe ? ",true" : ",false"; }
         o.kernel += ">";
     }
 }

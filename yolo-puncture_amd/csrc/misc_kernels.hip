@@ -385,6 +385,7 @@ static hipError_t launch_dwconv_t(const DwParams& p, hipStream_t st) {
 }
 
 hipError_t launch_dwconv(const DwParams& p, int dtype, hipStream_t st) {
+    if (dwconv_mfma_valid(p, dtype)) return launch_dwconv_mfma(p, st);
     return dtype == DT_BF16 ? launch_dwconv_t<__bf16>(p, st) : launch_dwconv_t<float>(p, st);
 }
 
