@@ -91,6 +91,15 @@ int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev
              int retina, uint8_t* masks_out, int64_t* id_out, int32_t* kept_out, int suppress_small,
              int min_area, void* stream);
 
+/* LetterBox on the device (the step before the network inside `.predict`; reference call sites yolo_seg/app.py:86-91,
+ * [U] ultralytics LetterBox = cv2.resize INTER_LINEAR + cv2.copyMakeBorder(114)). Engine-free, pure function of its
+ * arguments; bit-exact with the fixed-point 8-bit bilinear resize the oracle restates.
+ *    src_dev: uint8 [h0,w0,3] (HWC, any channel order)      dst_dev: uint8 [out_h,out_w,3]
+ *    the resized image (new_h x new_w; resize skipped when equal to h0 x w0) lands at (top,left), the rest is pad_value.
+ *    The geometry is the caller's (LetterBox arithmetic is host integer math: predictor.py / hostops.letterbox_geometry). */
+int yp_letterbox(const uint8_t* src_dev, int h0, int w0, uint8_t* dst_dev, int out_h, int out_w, int new_h, int new_w,
+                 int top, int left, int pad_value, void* stream);
+
 /* -- introspection (tests, bench): the planned op list for an input shape; host only. */
 int yp_plan(yp_engine* e, int B, int H, int W);            /* (re)build the plan; returns #ops or <0 */
 int yp_op_info(const yp_engine* e, int i, char* name, int name_cap, int* kind, double* flops,

@@ -126,3 +126,30 @@ def test_mask_kernels_bit_level(ckpt):
             assert torch.equal(ids.cpu(), wi)
             assert [k for k in kept.cpu().tolist() if k > 0] == [a for a, _, _ in winfo]
     eng.close()
+
+
+@pytest.mark.parametrize("h0,w0", [(720, 1280), (1080, 810), (360, 640), (640, 640), (97, 211), (1333, 777), (33, 1000), (480, 640)])
+def test_device_letterbox_bit_exact(h0, w0):
+    """yp_letterbox (HIP) against the oracle's restatement of LetterBox = cv2.resize(INTER_LINEAR, 8-bit fixed point) +
+    copyMakeBorder(114): integer work, so the bar is bit-exact - down-scaling, up-scaling, identity size, odd sizes,
+    both padding orientations."""
+    from yolo_puncture_amd import hostops
+    from yolo_puncture_amd.engine import letterbox_device
+    g = torch.Generator().manual_seed(h0 * 10007 + w0)
+    img = torch.randint(0, 256, (h0, w0, 3), generator=g, dtype=torch.uint8)
+    # structured content too: gradients make coefficient errors visible, noise makes index errors visible
+    img[: h0 // 2] = ((torch.arange(w0)[None, :, None] * 255) // max(w0 - 1, 1)).to(torch.uint8).expand(h0 // 2, w0, 3)
+    want, geo = po.letterbox(img.numpy())
+    assert geo == hostops.letterbox_geometry(h0, w0)
+    got = letterbox_device(img.cuda(), geo).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.array_equal(got, want), int((got != want).sum())
+
+
+def test_device_letterbox_rejects_bad_arguments():
+    from yolo_puncture_amd.engine import letterbox_device, YolopError
+    img = torch.zeros((8, 8, 3), dtype=torch.uint8)
+    with pytest.raises(ValueError):
+        letterbox_device(img, dict(out_h=8, out_w=8, new_h=8, new_w=8, top=0, left=0))          # host tensor
+    with pytest.raises(YolopError):
+        letterbox_device(img.cuda(), dict(out_h=8, out_w=8, new_h=9, new_w=8, top=0, left=0))   # does not fit

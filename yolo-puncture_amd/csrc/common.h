@@ -177,6 +177,8 @@ hipError_t launch_dwconv_mfma(const DwParams& p, hipStream_t st);
 hipError_t launch_upsample(const UpParams& p, int dtype, hipStream_t st);
 hipError_t launch_attention(const AttnParams& p, int dtype, hipStream_t st);
 hipError_t launch_head(const HeadParams& p, hipStream_t st);
+hipError_t launch_letterbox(const uint8_t* src, int h0, int w0, uint8_t* dst, int out_h, int out_w, int new_h, int new_w, int top,
+                            int left, int pad, hipStream_t st);
 size_t head_scratch_bytes(int B, int A);
 hipError_t head_read_clocks(unsigned long long* out8);
 

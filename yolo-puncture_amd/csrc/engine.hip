@@ -1131,6 +1131,17 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     return YP_OK;
 }
 
+int yp_letterbox(const uint8_t* src_dev, int h0, int w0, uint8_t* dst_dev, int out_h, int out_w, int new_h, int new_w, int top, int left,
+                 int pad_value, void* stream) {
+    if (!src_dev || !dst_dev) return fail(YP_ERR_ARG, "yp_letterbox: null buffer");
+    if (h0 <= 0 || w0 <= 0 || new_h <= 0 || new_w <= 0 || out_h <= 0 || out_w <= 0 || top < 0 || left < 0 || top + new_h > out_h ||
+        left + new_w > out_w || pad_value < 0 || pad_value > 255)
+        return fail(YP_ERR_ARG, "yp_letterbox: bad geometry %dx%d -> %dx%d at (%d,%d) in %dx%d", h0, w0, new_h, new_w, top, left, out_h, out_w);
+    if ((long)h0 * w0 * 3 >= (1l << 31) || (long)out_h * out_w * 3 >= (1l << 31)) return fail(YP_ERR_ARG, "yp_letterbox: image too large");
+    HIPCHK(launch_letterbox(src_dev, h0, w0, dst_dev, out_h, out_w, new_h, new_w, top, left, pad_value, (hipStream_t)stream));
+    return YP_OK;
+}
+
 int yp_debug_head_clocks(uint64_t* out8) {
     if (!out8) return fail(YP_ERR_ARG, "yp_debug_head_clocks: null output");
     HIPCHK(hipDeviceSynchronize());

@@ -66,6 +66,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_debug_force_conv_cfg.argtypes = [C.c_int]
     lib.yp_debug_ablation.argtypes = [C.c_int]
     lib.yp_debug_head_clocks.argtypes = [C.POINTER(C.c_uint64)]
+    lib.yp_letterbox.argtypes = [vp, C.c_int, C.c_int, vp] + [C.c_int] * 7 + [vp]
+    lib.yp_letterbox.restype = C.c_int
     for fn in ("yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight", "yp_finalize",
                "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output", "yp_tensor_count",
                "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op", "yp_tensor_write",
@@ -79,11 +81,31 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks"]
+           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_letterbox"]
 
 
 def _stream_ptr(device: torch.device) -> int:
     return int(torch.cuda.current_stream(device).cuda_stream)
+
+
+def letterbox_device(src: torch.Tensor, geo: dict, out: Optional[torch.Tensor] = None, pad_value: int = 114) -> torch.Tensor:
+    """LetterBox on the GPU (yp_letterbox): `src` uint8 cuda [h0,w0,3], `geo` from hostops.letterbox_geometry ->
+    uint8 cuda [out_h,out_w,3] (written into `out` when given, e.g. a row of the batch tensor)."""
+    if not (src.is_cuda and src.dtype == torch.uint8 and src.dim() == 3 and src.shape[2] == 3 and src.is_contiguous()):
+        raise ValueError("letterbox_device needs a contiguous uint8 CUDA tensor [H,W,3]")
+    oh, ow = int(geo["out_h"]), int(geo["out_w"])
+    if out is None:
+        out = torch.empty((oh, ow, 3), dtype=torch.uint8, device=src.device)
+    if not (out.is_cuda and out.dtype == torch.uint8 and tuple(out.shape) == (oh, ow, 3) and out.is_contiguous()):
+        raise ValueError(f"letterbox_device: output must be a contiguous uint8 CUDA tensor [{oh},{ow},3]")
+    lib = load_library()
+    with torch.cuda.device(src.device):
+        rc = lib.yp_letterbox(C.c_void_p(src.data_ptr()), int(src.shape[0]), int(src.shape[1]), C.c_void_p(out.data_ptr()), oh, ow,
+                              int(geo["new_h"]), int(geo["new_w"]), int(geo["top"]), int(geo["left"]), int(pad_value),
+                              C.c_void_p(_stream_ptr(src.device)))
+    if rc != 0:
+        raise YolopError(lib.yp_last_error().decode())
+    return out
 
 
 class Engine:

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import hostops
-from .engine import Engine
+from .engine import Engine, letterbox_device
 from .weights import read_ultralytics_pt, synthetic_state
 
 _ENGINE_CACHE: Dict[tuple, Engine] = {}
@@ -244,14 +244,18 @@ class YOLO:
         results: List[Results] = []
         # frames that letterbox to the same shape run as one batch
         groups: Dict[Tuple[int, int], List[int]] = {}
-        lb = []
+        geos = []
         for i, im in enumerate(imgs):
-            boxed, geo = hostops.letterbox(im, imgsz)
-            lb.append((boxed, geo))
-            groups.setdefault(boxed.shape[:2], []).append(i)
+            geo = hostops.letterbox_geometry(im.shape[0], im.shape[1], imgsz)
+            geos.append(geo)
+            groups.setdefault((geo["out_h"], geo["out_w"]), []).append(i)
         out_by_index: Dict[int, Results] = {}
         for (H, W), idxs in groups.items():
-            batch = torch.from_numpy(np.stack([lb[i][0] for i in idxs])).to(dev, non_blocking=True)
+            # the raw frame goes up once; resize + pad-114 run on the device straight into the batch tensor (yp_letterbox)
+            batch = torch.empty((len(idxs), H, W, 3), dtype=torch.uint8, device=dev)
+            for bi, i in enumerate(idxs):
+                raw = torch.from_numpy(np.ascontiguousarray(imgs[i])).to(dev, non_blocking=True)
+                letterbox_device(raw, geos[i], out=batch[bi])
             out = eng.forward(batch)
             det = out["det"]
             for bi, i in enumerate(idxs):
@@ -289,9 +293,11 @@ class YOLO:
         out_hw = (oh, ow) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
         eng = self._engine()
         dev = torch.device("cuda", self._dev_index)
-        boxed, _ = hostops.letterbox(im, imgsz)
-        H, W = boxed.shape[:2]
-        out = eng.forward(torch.from_numpy(boxed[None]).to(dev))
+        geo = hostops.letterbox_geometry(oh, ow, imgsz)
+        H, W = geo["out_h"], geo["out_w"]
+        batch = torch.empty((1, H, W, 3), dtype=torch.uint8, device=dev)
+        letterbox_device(torch.from_numpy(np.ascontiguousarray(im)).to(dev), geo, out=batch[0])
+        out = eng.forward(batch)
         d = out["det"][0]
         keep = d[:, 4] > conf
         d = d[keep]
