@@ -32,7 +32,7 @@ template <int BK> __device__ __forceinline__ int swz_p(int row) {
     return BK == 32 ? (((row >> 2) & 1) << 1) : ((row >> 1) & 7);
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32, bool WRES, bool PIPE>
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32, bool WRES, bool PIPE, bool PP>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvParams p, const int mtiles, const int ntiles, const int G) {
     constexpr int NW = WGM * WGN;
     constexpr int CPR = BK / 8;
@@ -197,6 +197,144 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
             for (int b = 0; b < FM; ++b) xf[ss][b] = *(const bf16x8*)(sb + aoff[ss] + b * 16 * RB);
         }
     };
+    f32x4 acc[FN][FM];
+    auto reset_acc = [&]() {
+#pragma unroll
+        for (int a = 0; a < FN; ++a)
+#pragma unroll
+            for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};   // bias rides in the accumulator
+    };
+    // epilogue of one tile: exactly S buffer stores per wave
+    auto store_tile = [&](int tile) {
+    const int m0 = tile * BM;
+        uint2 rres[FM][FN];
+        if (HAS_RES) {
+#pragma unroll
+            for (int b = 0; b < FM; ++b) {
+                const int m = m0 + wm * WM + b * 16 + fr;
+#pragma unroll
+                for (int a = 0; a < FN; ++a) {
+                    const int co = n0 + wn * WN + a * 16 + fc * 4;
+                    rres[b][a] = (m < p.M && co < p.Cout)
+                                     ? *(const uint2*)((const __bf16*)p.res + (size_t)m * p.res_stride + p.res_coff + co)
+                                     : make_uint2(0u, 0u);
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < FM; ++b) {
+            const int m = m0 + wm * WM + b * 16 + fr;
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int co = n0 + wn * WN + a * 16 + fc * 4;
+                const bool ok = (m < p.M) && (co < p.Cout) && (p.dbg != 1);
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float tt = acc[a][b][i];
+                    if (p.act == ACT_SILU) tt = silu_f2(tt);
+                    v[i] = tt;
+                }
+                if (HAS_RES) {
+                    const uint2 rr = rres[b][a];
+                    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+                }
+                if (OUT_F32) {
+                    const unsigned off = ok ? ((unsigned)m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 4u : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(v[0], v[1], v[2], v[3])), yrs, off, 0, 0);
+                } else {
+                    const unsigned off = ok ? ((unsigned)m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 2u : OOB;
+                    __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    __builtin_amdgcn_raw_buffer_store_b64(*(const __attribute__((ext_vector_type(2))) unsigned*)o, yrs, off, 0, 0);
+                }
+            }
+        }
+    };
+
+    if constexpr (PP) {
+        // ---- ping-pong schedule (8 waves: two per SIMD). Waves 0-3 and waves 4-7 alternate roles between barriers: in
+        // interval A(g) the first half issues its LDS-DMA pieces of stage g+NS-1 and reads its fragments of stage g while the
+        // second half runs the MFMAs of k-step g-1; in B(g) the roles swap. Every SIMD then always has one wave in a matrix
+        // burst and its partner in a load segment, instead of both bursting and both loading together (PMC: 32 % matrix pipe).
+        // Both halves pass the same two barriers per k-step. Visibility of stage g+1: every wave waits for its own pieces
+        // before the barrier that ends B(g); ops younger than L(g+1) there: L(g+2..g+NS-1) (the last one issued in this
+        // k-step) plus the stores of the tile ends of the last NS-1 (first half) / NS-2 (second half) k-steps.
+        static_assert(NW == 8 && !PIPE, "ping-pong pairs the two waves of each SIMD");
+        static_assert((NS - 2) * LPW + (NS - 1) * S < 64, "vmcnt immediate");
+        if (!WRES) {
+            wait_vmp<(NS - 2) * LPW>();           // stage 0 landed
+            __builtin_amdgcn_s_barrier();
+        }
+        auto mfma_all = [&]() {
+#pragma unroll
+            for (int ss = 0; ss < KSUB; ++ss)
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int b = 0; b < FM; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cw[ss][a], cx[ss][b], acc[a][b], 0, 0, 0);
+        };
+        auto wait_stage = [&](int k) {
+            if (k == 0) wait_vmp<(NS - 2) * LPW>();
+            else if (k == 1) wait_vmp<(NS - 2) * LPW + S>();
+            else if (k == 2) wait_vmp<(NS - 2) * LPW + 2 * S>();
+            else wait_vmp<(NS - 2) * LPW + (NS >= 4 ? 3 : 2) * S>();
+        };
+        reset_acc();
+        if (wave < NW / 2) {
+            for (int tile = j0; tile < mtiles; tile += G) {
+                for (int kt = 0; kt < nk; ++kt) {
+                    issue_next();
+                    epmask <<= 1;
+                    load_frags(rslot, kt, cw, cx);
+                    rslot = (rslot + 1 == NS) ? 0 : rslot + 1;
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                                  // end of A(g)
+                    mfma_all();
+                    if (kt == nk - 1) {
+                        store_tile(tile);
+                        reset_acc();
+                        epmask |= 1u;
+                    }
+                    wait_stage(__builtin_popcount(epmask & ((1u << (NS - 1)) - 1u)));
+                    __builtin_amdgcn_s_barrier();                                  // end of B(g)
+                }
+            }
+        } else {
+            int prev_tile = -1;
+            bool prev_last = false;
+            for (int tile = j0; tile < mtiles; tile += G) {
+                for (int kt = 0; kt < nk; ++kt) {
+                    if (prev_tile >= 0) {
+                        mfma_all();
+                        if (prev_last) {
+                            store_tile(prev_tile);
+                            reset_acc();
+                            epmask |= 1u;
+                        }
+                    }
+                    __builtin_amdgcn_s_barrier();                                  // end of A(g)
+                    issue_next();
+                    load_frags(rslot, kt, cw, cx);
+                    rslot = (rslot + 1 == NS) ? 0 : rslot + 1;
+                    wait_stage(__builtin_popcount(epmask & ((1u << (NS - 2)) - 1u)));
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();                                  // end of B(g)
+                    epmask <<= 1;
+                    prev_tile = tile;
+                    prev_last = (kt == nk - 1);
+                }
+            }
+            if (prev_tile >= 0) {
+                mfma_all();
+                store_tile(prev_tile);
+            }
+        }
+        wait_vmp<0>();
+        return;
+    }
+
     if (PIPE) {
         if (!WRES) {
             wait_vmp<(NS - 2) * LPW>();           // stage 0 landed
@@ -206,12 +344,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
         rslot = 1;
     }
     for (int tile = j0; tile < mtiles; tile += G) {
-        f32x4 acc[FN][FM];
-#pragma unroll
-        for (int a = 0; a < FN; ++a)
-#pragma unroll
-            for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};   // bias rides in the accumulator
-
+        reset_acc();
         if (PIPE) {
             for (int kt = 0; kt < nk; ++kt) {
                 {
@@ -271,60 +404,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
             rslot = (rslot + 1 == NS) ? 0 : rslot + 1;
         }
 
-        // ---- epilogue: exactly S buffer stores per wave ---------------------------------------------------------
-        {
-            const int m0 = tile * BM;
-            uint2 rres[FM][FN];
-            if (HAS_RES) {
-#pragma unroll
-                for (int b = 0; b < FM; ++b) {
-                    const int m = m0 + wm * WM + b * 16 + fr;
-#pragma unroll
-                    for (int a = 0; a < FN; ++a) {
-                        const int co = n0 + wn * WN + a * 16 + fc * 4;
-                        rres[b][a] = (m < p.M && co < p.Cout)
-                                         ? *(const uint2*)((const __bf16*)p.res + (size_t)m * p.res_stride + p.res_coff + co)
-                                         : make_uint2(0u, 0u);
-                    }
-                }
-            }
-#pragma unroll
-            for (int b = 0; b < FM; ++b) {
-                const int m = m0 + wm * WM + b * 16 + fr;
-#pragma unroll
-                for (int a = 0; a < FN; ++a) {
-                    const int co = n0 + wn * WN + a * 16 + fc * 4;
-                    const bool ok = (m < p.M) && (co < p.Cout) && (p.dbg != 1);
-                    float v[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float tt = acc[a][b][i];
-                        if (p.act == ACT_SILU) tt = silu_f2(tt);
-                        v[i] = tt;
-                    }
-                    if (HAS_RES) {
-                        const uint2 rr = rres[b][a];
-                        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-                        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-                    }
-                    if (OUT_F32) {
-                        const unsigned off = ok ? ((unsigned)m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 4u : OOB;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(v[0], v[1], v[2], v[3])), yrs, off, 0, 0);
-                    } else {
-                        const unsigned off = ok ? ((unsigned)m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 2u : OOB;
-                        __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-                        __builtin_amdgcn_raw_buffer_store_b64(*(const __attribute__((ext_vector_type(2))) unsigned*)o, yrs, off, 0, 0);
-                    }
-                }
-            }
-        }
+        store_tile(tile);
         epmask |= 1u;
     }
     wait_vmp<0>();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct DmaPCfg { int BM, BN, NW, BK, NS; const char* name; int wres; int pipe; };
+struct DmaPCfg { int BM, BN, NW, BK, NS; const char* name; int wres; int pipe; int pp; };
 static const DmaPCfg kP[] = {
     {128, 32, 4, 32, 4, "conv_dma_p_kernel<128,32,4,1,32,4>"},     // 0
     {128, 64, 4, 32, 4, "conv_dma_p_kernel<128,64,2,2,32,4>"},     // 1
@@ -361,6 +448,15 @@ static const DmaPCfg kP[] = {
     {64, 64, 4, 64, 4, "conv_dma_p_kernel<64,64,2,2,64,4,W,P>", 1, 1},       // 30
     {128, 64, 4, 64, 4, "conv_dma_p_kernel<128,64,2,2,64,4,W,P>", 1, 1},     // 31
     {128, 128, 8, 64, 4, "conv_dma_p_kernel<128,128,4,2,64,4,P>", 0, 1},     // 32
+    // ping-pong forms (ids 33..): the two waves of each SIMD alternate between a load segment and a matrix burst
+    {256, 128, 8, 32, 4, "conv_dma_p_kernel<256,128,4,2,32,4,Q>", 0, 0, 1},     // 33
+    {256, 64, 8, 32, 4, "conv_dma_p_kernel<256,64,4,2,32,4,Q>", 0, 0, 1},       // 34
+    {128, 256, 8, 32, 4, "conv_dma_p_kernel<128,256,2,4,32,4,Q>", 0, 0, 1},     // 35
+    {128, 128, 8, 64, 4, "conv_dma_p_kernel<128,128,4,2,64,4,Q>", 0, 0, 1},     // 36
+    {128, 64, 8, 64, 4, "conv_dma_p_kernel<128,64,4,2,64,4,Q>", 0, 0, 1},       // 37
+    {128, 128, 8, 64, 4, "conv_dma_p_kernel<128,128,4,2,64,4,W,Q>", 1, 0, 1},   // 38
+    {256, 64, 8, 64, 3, "conv_dma_p_kernel<256,64,4,2,64,3,W,Q>", 1, 0, 1},     // 39
+    {256, 128, 8, 64, 3, "conv_dma_p_kernel<256,128,4,2,64,3,Q>", 0, 0, 1},     // 40 (3 x 48 KiB stages)
 };
 constexpr int kNumP = (int)(sizeof(kP) / sizeof(kP[0]));
 int conv_dma_p_num_cfgs() { return kNumP; }
@@ -384,7 +480,7 @@ bool conv_dma_p_cfg_valid(const ConvParams& p, int c) {
 }
 const char* conv_dma_p_kernel_name(int c) { return kP[c].name; }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32, bool WRES, bool PIPE>
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool HAS_RES, bool OUT_F32, bool WRES, bool PIPE, bool PP>
 static hipError_t launch_p_var(const ConvParams& p, hipStream_t st) {
     const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
     const size_t sh = WRES ? ((size_t)NS * BM * BK * 2 + 1024 + (size_t)BN * p.Kpad * 2) : ((size_t)NS * (BM + BN) * BK * 2 + 1024);
@@ -392,7 +488,7 @@ static hipError_t launch_p_var(const ConvParams& p, hipStream_t st) {
     int G = (256 * per_cu) / ntiles;
     if (G < 1) G = 1;
     if (G > mtiles) G = mtiles;
-    auto kern = conv_dma_p_kernel<BM, BN, WGM, WGN, BK, NS, HAS_RES, OUT_F32, WRES, PIPE>;
+    auto kern = conv_dma_p_kernel<BM, BN, WGM, WGN, BK, NS, HAS_RES, OUT_F32, WRES, PIPE, PP>;
     static bool attr = false;
     if (!attr && (WRES || sh > 64 * 1024)) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(WRES ? 160 * 1024 : sh));
@@ -402,11 +498,11 @@ static hipError_t launch_p_var(const ConvParams& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3(WGM * WGN * 64), sh, st, p, mtiles, ntiles, G);
     return hipGetLastError();
 }
-template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool WRES = false, bool PIPE = false>
+template <int BM, int BN, int WGM, int WGN, int BK, int NS, bool WRES = false, bool PIPE = false, bool PP = false>
 static hipError_t launch_p_one(const ConvParams& p, hipStream_t st) {
-    if (p.out_f32) return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, true, WRES, PIPE>(p, st);
-    if (p.res) return launch_p_var<BM, BN, WGM, WGN, BK, NS, true, false, WRES, PIPE>(p, st);
-    return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, false, WRES, PIPE>(p, st);
+    if (p.out_f32) return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, true, WRES, PIPE, PP>(p, st);
+    if (p.res) return launch_p_var<BM, BN, WGM, WGN, BK, NS, true, false, WRES, PIPE, PP>(p, st);
+    return launch_p_var<BM, BN, WGM, WGN, BK, NS, false, false, WRES, PIPE, PP>(p, st);
 }
 
 hipError_t launch_conv_dma_p(const ConvParams& p, int c, hipStream_t st) {
@@ -443,7 +539,15 @@ hipError_t launch_conv_dma_p(const ConvParams& p, int c, hipStream_t st) {
         case 29: return launch_p_one<128, 128, 4, 2, 64, 4, true, true>(p, st);
         case 30: return launch_p_one<64, 64, 2, 2, 64, 4, true, true>(p, st);
         case 31: return launch_p_one<128, 64, 2, 2, 64, 4, true, true>(p, st);
-        default: return launch_p_one<128, 128, 4, 2, 64, 4, false, true>(p, st);
+        case 32: return launch_p_one<128, 128, 4, 2, 64, 4, false, true>(p, st);
+        case 33: return launch_p_one<256, 128, 4, 2, 32, 4, false, false, true>(p, st);
+        case 34: return launch_p_one<256, 64, 4, 2, 32, 4, false, false, true>(p, st);
+        case 35: return launch_p_one<128, 256, 2, 4, 32, 4, false, false, true>(p, st);
+        case 36: return launch_p_one<128, 128, 4, 2, 64, 4, false, false, true>(p, st);
+        case 37: return launch_p_one<128, 64, 4, 2, 64, 4, false, false, true>(p, st);
+        case 38: return launch_p_one<128, 128, 4, 2, 64, 4, true, false, true>(p, st);
+        case 39: return launch_p_one<256, 64, 4, 2, 64, 3, true, false, true>(p, st);
+        default: return launch_p_one<256, 128, 4, 2, 64, 3, false, false, true>(p, st);
     }
 }
 

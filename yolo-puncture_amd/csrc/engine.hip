@@ -697,12 +697,13 @@ static void finish_kernel_names(yp_engine& e) {
         if (o.kernel.find("_p_kernel<") == std::string::npos || o.kernel.find(",false>") != std::string::npos || o.kernel.find(",true>") != std::string::npos) continue;
         const bool f32 = (o.kind == OP_CONV) && e.tensors[o.out.t].f32 && e.dtype == DT_BF16;
         const bool res = o.res.t >= 0;
-        bool wres = false, pipe = false;
+        bool wres = false, pipe = false, pp = false;
         if (o.kernel.size() > 3 && o.kernel.compare(o.kernel.size() - 3, 3, ",P>") == 0) { pipe = true; o.kernel.erase(o.kernel.size() - 3); o.kernel += ">"; }
+        if (o.kernel.size() > 3 && o.kernel.compare(o.kernel.size() - 3, 3, ",Q>") == 0) { pp = true; o.kernel.erase(o.kernel.size() - 3); o.kernel += ">"; }
         if (o.kernel.size() > 3 && o.kernel.compare(o.kernel.size() - 3, 3, ",W>") == 0) { wres = true; o.kernel.erase(o.kernel.size() - 3); }
         else o.kernel.pop_back();
         o.kernel += f32 ? ",false,true" : (res ? ",true,false" : ",false,false");
-        if (o.kernel.find("conv_dma_p_kernel") != std::string::npos) { o.kernel += wres ? ",true" : ",false"; o.kernel += pipe ? ",true" : ",false"; }
+        if (o.kernel.find("conv_dma_p_kernel") != std::string::npos) { o.kernel += wres ? ",true" : ",false"; o.kernel += pipe ? ",true" : ",false"; o.kernel += pp ? ",true" : ",false"; }
         o.kernel += ">";
     }
 }
