@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-lanes", action="store_true", help="hipGraph without the concurrent head-branch lanes (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (rehearsal of the N>1 path on a 1-GPU box; launch under torch.distributed.run)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -110,7 +111,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or a.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)   # RCCL over xGMI
@@ -126,19 +128,33 @@ def main():
     out = dict(det=torch.empty((B, 300, 6), dtype=torch.float32, device=dev),
                idx=torch.empty((B, 300), dtype=torch.int32, device=dev),
                coeff=torch.empty((B, 300, 32), dtype=torch.float32, device=dev) if a.seg else None)
-    gathered = torch.empty((world * B, 300, 6), dtype=torch.float32, device=dev) if world > 1 else None
+    # N>1: two detection buffers so that the all-gather of step i (RCCL stream) overlaps the forward of step i+1
+    # (the engine's hipGraph is keyed on its output pointers, so it keeps ONE output buffer; the 230 KB of detections are
+    # copied to alternating send buffers)
+    send = [torch.empty_like(out["det"]) for _ in range(2)] if use_dist else None
+    gath = [torch.empty((world * B, 300, 6), dtype=torch.float32, device=dev) for _ in range(2)] if use_dist else None
+    pending = [None, None]
+    nstep = [0]
     eng.set_graph(not a.no_graph)
     if a.no_lanes and not a.no_graph:
         eng._chk(eng.lib.yp_set_graph(eng._h, 2))
 
     def step():
         eng.forward(frames, out)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, out["det"])
+        if use_dist:
+            i = nstep[0] & 1
+            nstep[0] += 1
+            if pending[i] is not None:
+                pending[i].wait()                   # the gather that last used this pair of buffers has finished
+            send[i].copy_(out["det"])
+            pending[i] = dist.all_gather_into_tensor(gath[i], send[i], async_op=True)
 
     def sync():
+        for h in pending:
+            if h is not None:
+                h.wait()
         torch.cuda.synchronize(dev)
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -150,7 +166,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -209,7 +225,9 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
+        if rank == 0 and not (torch.equal(gath[0][:B], out["det"]) and torch.equal(gath[1][:B], out["det"])):
+            raise SystemExit("all-gather returned different detections than the local shard")
         dist.barrier()
         dist.destroy_process_group()
     eng.close()
