@@ -7,6 +7,9 @@
 namespace yp {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// bf16 storage: v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~12 instructions) - same form as the conv epilogues
+__device__ __forceinline__ float silu_q(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+template <typename T> __device__ __forceinline__ float silu_t(float x) { return sizeof(T) == 2 ? silu_q(x) : silu_f(x); }
 
 template <typename T> struct Vec8;
 template <> struct Vec8<__bf16> {
@@ -119,22 +122,21 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
     unsigned char* Xs = lds;
     unsigned char* Ws = lds + 256 * 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const long M = (long)p.B * p.Ho * p.Wo;
-    const long m = (long)blockIdx.x * 256 + tid;
+    const int M = p.B * p.Ho * p.Wo;                     // < 2^31 (checked by the launcher): 32-bit pixel arithmetic
+    const int m = (int)blockIdx.x * 256 + tid;
     // ---- im2col row of this thread's pixel ---------------------------------------------------------------
     {
         __attribute__((aligned(16))) __bf16 row[32];
 #pragma unroll
         for (int i = 0; i < 32; ++i) row[i] = (__bf16)0.f;
         if (m < M) {
-            const int wo = (int)(m % p.Wo);
-            const int ho = (int)((m / p.Wo) % p.Ho);
-            const int b = (int)(m / ((long)p.Wo * p.Ho));
+            const int wo = m % p.Wo;
+            const int ho = (m / p.Wo) % p.Ho;
+            const int b = m / (p.Wo * p.Ho);
             const uint8_t* xb = p.x + (size_t)b * p.H * p.W * 3;
             const int rowbytes = p.W * 3;                         // multiple of 4 (W is a multiple of 32)
             const int sb = (wo * 2 - 1) * 3;                      // first byte of the 9-byte (3 px x BGR) segment; -3 at wo=0
             const int ab = sb & ~3;                               // aligned dword holding it (floor, also for -3 -> -4)
-            const int sh = (sb - ab) * 8;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int hi = ho * 2 - 1 + ky;
@@ -148,23 +150,22 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
                     d[k] = *(const unsigned*)(rp + (ok ? o : 0));
                     d[k] = ok ? d[k] : 0u;
                 }
-                // 96-bit value >> sh : bytes 0..8
-                const unsigned long long lo = ((unsigned long long)d[1] << 32) | d[0];
-                const unsigned long long hi64 = ((unsigned long long)d[2] << 32) | d[1];
-                const unsigned long long b07 = sh ? ((lo >> sh) | ((unsigned long long)d[2] << (64 - sh))) : lo;   // bytes 0..7
-                const unsigned b8 = (unsigned)((hi64 >> sh) >> 32) & 0xffu;                                         // byte 8
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int wi = wo * 2 - 1 + kx;
-                    const bool ok = (unsigned)wi < (unsigned)p.W;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const int bi = kx * 3 + c;
-                        const unsigned byte = (bi < 8) ? (unsigned)((b07 >> (8 * bi)) & 0xffu) : b8;
-                        const float v = ok ? ((float)byte / 255.0f) : 0.f;
-                        row[(ky * 3 + kx) * 3 + c] = (__bf16)v;
-                    }
-                }
+                // the 9 bytes (3 px x BGR) of this tap row, byte-aligned into three dwords (v_alignbyte_b32); a pixel left
+                // of the image (kx = 0 at wo = 0) is zero padding. The right neighbour 2*wo+1 is always inside (W even).
+                const unsigned sbytes = (unsigned)(sb - ab);
+                unsigned w0 = __builtin_amdgcn_alignbyte(d[1], d[0], sbytes);      // bytes 0..3
+                const unsigned w1 = __builtin_amdgcn_alignbyte(d[2], d[1], sbytes); // bytes 4..7
+                const unsigned w2 = __builtin_amdgcn_alignbyte(0u, d[2], sbytes);   // byte 8
+                if (wo == 0) w0 &= 0xff000000u;
+                // x / 255 then bf16: for all 256 byte values bf16(x * fl(1/255)) == bf16(x / 255) (checked exhaustively), so the
+                // bf16 stem multiplies; byte -> float is one v_cvt_f32_ubyteN
+                const float k = 1.0f / 255.0f;
+                __bf16* rr = row + ky * 9;
+                rr[0] = (__bf16)((float)(w0 & 0xffu) * k);          rr[1] = (__bf16)((float)((w0 >> 8) & 0xffu) * k);
+                rr[2] = (__bf16)((float)((w0 >> 16) & 0xffu) * k);  rr[3] = (__bf16)((float)(w0 >> 24) * k);
+                rr[4] = (__bf16)((float)(w1 & 0xffu) * k);          rr[5] = (__bf16)((float)((w1 >> 8) & 0xffu) * k);
+                rr[6] = (__bf16)((float)((w1 >> 16) & 0xffu) * k);  rr[7] = (__bf16)((float)(w1 >> 24) * k);
+                rr[8] = (__bf16)((float)(w2 & 0xffu) * k);
             }
         }
         const uint4* r4 = (const uint4*)row;
@@ -190,12 +191,12 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
         for (int b = 0; b < 4; ++b) {
             f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[b], acc, 0, 0, 0);
-            const long mm = (long)blockIdx.x * 256 + wave * 64 + b * 16 + fr;
+            const int mm = (int)blockIdx.x * 256 + wave * 64 + b * 16 + fr;
             if (mm >= M) continue;
             float v[4] = {acc[0] + bs.x, acc[1] + bs.y, acc[2] + bs.z, acc[3] + bs.w};
             if (p.act == ACT_SILU) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+                for (int r = 0; r < 4; ++r) v[r] = silu_q(v[r]);
             }
             __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             *(uint2*)((__bf16*)p.y + (size_t)mm * p.y_stride + p.y_coff + co) = *(const uint2*)o;
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
 hipError_t launch_stem(const StemParams& p, int dtype, hipStream_t st) {
     const long total = (long)p.B * p.Ho * p.Wo * (p.C0 / 8);
     const int blk = 256;
-    if (dtype == DT_BF16 && p.wpk && (p.C0 % 16) == 0 && p.C0 <= 80 && (p.y_stride & 3) == 0 && (p.y_coff & 3) == 0) {
+    if (dtype == DT_BF16 && p.wpk && (p.C0 % 16) == 0 && p.C0 <= 80 && (p.y_stride & 3) == 0 && (p.y_coff & 3) == 0 &&
+        (long)p.B * p.Ho * p.Wo + 256 < (1l << 31)) {
         const long M = (long)p.B * p.Ho * p.Wo;
         const unsigned grid = (unsigned)((M + 255) / 256);
         const __bf16* w = (const __bf16*)p.wpk;
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const DwParams p) {
     }
     if (p.act == ACT_SILU) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = silu_f(acc[j]);
+        for (int j = 0; j < 8; ++j) acc[j] = silu_t<T>(acc[j]);
     }
     if (p.res) {
         Vec8<T> rv;
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(256) void dwconv_row_kernel(const DwParams p) {
         const size_t pix = ((size_t)b * p.Ho + ho) * p.Wo + wo;
         if (p.act == ACT_SILU) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc[o][j] = silu_f(acc[o][j]);
+            for (int j = 0; j < 8; ++j) acc[o][j] = silu_t<T>(acc[o][j]);
         }
         if (p.res) {
             Vec8<T> rv;
