@@ -11,7 +11,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 // mode 0: LDS-DMA ; mode 1: global->VGPR (sum kept live)
 // shape: row_bytes in {64,128,256,1024}: a wave's 1 KiB is (1024/row_bytes) rows, consecutive rows `row_stride` bytes apart
 template <int MODE>
-__global__ __launch_bounds__(512) void dma_kernel(const unsigned char* src, size_t src_bytes, int row_bytes, int row_stride,
+__global__ __launch_bounds__(1024) void dma_kernel(const unsigned char* src, size_t src_bytes, int row_bytes, int row_stride,
                                                   size_t wave_stride, size_t iter_stride, int iters, float* sink) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
@@ -42,7 +42,7 @@ int main() {
     const size_t big = 1ull << 30;   // 1 GiB source
     unsigned char* src; float* sink;
     CHECK(hipMalloc(&src, big)); CHECK(hipMemset(src, 1, big)); CHECK(hipMalloc(&sink, 4));
-    CHECK(hipFuncSetAttribute((const void*)dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    CHECK(hipFuncSetAttribute((const void*)dma_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     struct Case { const char* name; int row_bytes, row_stride; size_t footprint; };
     // footprint: bytes the whole grid cycles through (small -> L2 hits after the first pass)
@@ -53,8 +53,8 @@ int main() {
         {"64B rows  / HBM 1GB          ", 64, 256, big},        {"128B rows / HBM 1GB          ", 128, 256, big},
         {"1KB contig/ HBM 1GB          ", 1024, 1024, big},
     };
-    for (int nwaves : {4, 8}) {
-        for (int mode = 0; mode < 2; ++mode) {
+    for (int nwaves : {2, 4, 8, 12, 16}) {
+        for (int mode = 0; mode < 1; ++mode) {
             for (const Case& c : cases) {
                 const int grid = 256, iters = 256;
                 // every wave walks its own stream; per-iteration stride chosen so the grid sweeps `footprint`
@@ -64,8 +64,8 @@ int main() {
                 const size_t fp = c.footprint;
                 if (iter_stride >= fp) iter_stride = 0;                                     // tiny footprint: re-read the same lines
                 auto launch = [&]() {
-                    if (mode == 0) hipLaunchKernelGGL(dma_kernel<0>, dim3(grid), dim3(nwaves * 64), 64 * 1024, 0, src, fp, c.row_bytes, c.row_stride, wave_stride, iter_stride, iters, sink);
-                    else hipLaunchKernelGGL(dma_kernel<1>, dim3(grid), dim3(nwaves * 64), 64 * 1024, 0, src, fp, c.row_bytes, c.row_stride, wave_stride, iter_stride, iters, sink);
+                    if (mode == 0) hipLaunchKernelGGL(dma_kernel<0>, dim3(grid), dim3(nwaves * 64), 128 * 1024, 0, src, fp, c.row_bytes, c.row_stride, wave_stride, iter_stride, iters, sink);
+                    else hipLaunchKernelGGL(dma_kernel<1>, dim3(grid), dim3(nwaves * 64), 128 * 1024, 0, src, fp, c.row_bytes, c.row_stride, wave_stride, iter_stride, iters, sink);
                 };
                 launch(); CHECK(hipDeviceSynchronize());
                 CHECK(hipEventRecord(e0)); launch(); CHECK(hipEventRecord(e1)); CHECK(hipDeviceSynchronize());
