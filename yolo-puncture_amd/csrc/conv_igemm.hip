@@ -244,6 +244,7 @@ static int conv_tile_choice(const ConvParams& p) {
 static int halo_choice(const ConvParams& p, int dtype) {
     if (dtype != DT_BF16) return -1;
     auto valid = [&](int c) {
+        if (c >= 500) return conv_halo_s2_cfg_valid(p, c - 500);
         if (c >= 400) return conv_dma_lc_cfg_valid(p, c - 400);
         if (c >= 300) return conv_dma_p_cfg_valid(p, c - 300);
         if (c >= 200) return conv_halo_p_cfg_valid(p, c - 200);
@@ -259,6 +260,7 @@ static int halo_choice(const ConvParams& p, int dtype) {
 
 const char* conv_kernel_name(const ConvParams& p, int dtype) {
     const int h = halo_choice(p, dtype);
+    if (h >= 500) return conv_halo_s2_kernel_name(h - 500);
     if (h >= 400) return conv_dma_lc_kernel_name(h - 400);
     if (h >= 300) return conv_dma_p_kernel_name(h - 300);
     if (h >= 200) return conv_halo_p_kernel_name(h - 200);
@@ -291,6 +293,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t st) {
 
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st) {
     const int h = halo_choice(p, dtype);
+    if (h >= 500) return launch_conv_halo_s2(p, h - 500, st);
     if (h >= 400) return launch_conv_dma_lc(p, h - 400, st);
     if (h >= 300) return launch_conv_dma_p(p, h - 300, st);
     if (h >= 200) return launch_conv_halo_p(p, h - 200, st);

@@ -615,6 +615,7 @@ static int autotune(yp_engine& e) {
             for (int c = 0; c < conv_halo_num_cfgs(); ++c) if (conv_halo_cfg_valid(p, c)) cands.push_back(100 + c);
             for (int c = 0; c < conv_halo_p_num_cfgs(); ++c) if (conv_halo_p_cfg_valid(p, c)) cands.push_back(200 + c);
             for (int c = 0; c < conv_dma_p_num_cfgs(); ++c) if (conv_dma_p_cfg_valid(p, c)) cands.push_back(300 + c);
+            for (int c = 0; c < conv_halo_s2_num_cfgs(); ++c) if (conv_halo_s2_cfg_valid(p, c)) cands.push_back(500 + c);
             static const bool no_lc = [] { const char* v = std::getenv("YOLOP_NO_LC"); return v && *v == '1'; }();   // A/B switch
             for (int c = 0; !no_lc && c < conv_dma_lc_num_cfgs(); ++c) if (conv_dma_lc_cfg_valid(p, c)) cands.push_back(400 + c);
             for (int cc : cands) {
@@ -696,7 +697,7 @@ static DwPwParams dwpw_params(const yp_engine& e, const Op& c) {
 // the persistent conv kernels are additionally templated on <HAS_RES, OUT_F32>: make the reported symbol exact
 static void finish_kernel_names(yp_engine& e) {
     for (Op& o : e.ops) {
-        const bool lc = o.kernel.find("_lc_kernel<") != std::string::npos;
+        const bool lc = o.kernel.find("_lc_kernel<") != std::string::npos || o.kernel.find("_s2_kernel<") != std::string::npos;
         if ((o.kernel.find("_p_kernel<") == std::string::npos && !lc) || o.kernel.find(",false>") != std::string::npos || o.kernel.find(",true>") != std::string::npos) continue;
         const bool f32 = (o.kind == OP_CONV) && e.tensors[o.out.t].f32 && e.dtype == DT_BF16;
         const bool res = o.res.t >= 0;
