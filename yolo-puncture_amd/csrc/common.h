@@ -71,6 +71,8 @@ struct Op {
     int fuse_dw = -1;             // OP_CONV 1x1: index of the depthwise 3x3 op feeding it that can be fused in (graph pass)
     bool fused = false;           // plan decision: this conv runs as the fused dw->pw kernel
     bool skip = false;            // plan decision: this op's work is done by a fused consumer
+    int fold_up = -1;             // OP_CONV 1x1 on a [upsampled | skip] concat: index of the nearest-x2 upsample op it can absorb
+    bool folded = false;          // plan decision: the upsample is folded into this conv's input gather
     int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
 };
 
@@ -91,6 +93,9 @@ struct ConvParams {
     size_t x_bytes, w_bytes, y_bytes;           // extents of the x / packed-weight / y buffers (buffer descriptors)
     int cfg;                                    // conv_dma tile configuration (-1: heuristic)
     int dbg;                                    // timing ablations (tests/tools only): 1 = drop stores, 2 = drop pixel loads
+    // folded nearest-x2 upsample (1x1 convs on a [upsampled | skip] concat): input channels [0, x2_C) are read from the
+    // low-resolution tensor x2 at pixel (ho >> 1, wo >> 1) instead of from x; channels >= x2_C come from x as usual
+    const void* x2; size_t x2_bytes; int x2_stride, x2_coff, x2_C, x2_H, x2_W;
 };
 
 struct DwParams {

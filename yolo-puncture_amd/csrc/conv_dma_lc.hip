@@ -65,9 +65,10 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_dma_lc_kernel(cons
         const int lw = wave - NC;
         const int HoWo = p.Ho * p.Wo;
         const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t xrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2_C > 0 ? p.x2 : p.x), 0, (int)(p.x2_C > 0 ? p.x2_bytes : p.x_bytes), 0x00020000);
         const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
         // per-piece constants: piece q < A_INSTR is a pixel piece (16 rows of the im2col tile), else a weight piece
-        unsigned pconst[MAXP], pmask[MAXP];
+        unsigned pconst[MAXP], pmask[MAXP], pconst2[MAXP];     // pconst2: the pixel piece's rows in the folded-upsample source
         auto set_tile = [&](int mt) {
 #pragma unroll
             for (int j = 0; j < MAXP; ++j) {
@@ -82,6 +83,11 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_dma_lc_kernel(cons
                     if (p.ks == 1) {
                         base = (unsigned)(m * p.x_stride + p.x_coff) * 2u;
                         mask = 1u;
+                        if (p.x2_C > 0) {
+                            const int b = m / HoWo, r = m - b * HoWo;
+                            const int ho = r / p.Wo, wo = r - ho * p.Wo;
+                            pconst2[j] = (unsigned)(((b * p.x2_H + (ho >> 1)) * p.x2_W + (wo >> 1)) * p.x2_stride + p.x2_coff) * 2u + (unsigned)c * 16u;
+                        }
                     } else {
                         const int b = m / HoWo, r = m - b * HoWo;
                         const int ho = r / p.Wo, wo = r - ho * p.Wo;
@@ -115,12 +121,13 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_dma_lc_kernel(cons
             const unsigned tapoff = (unsigned)(((is_ky * p.W + is_kx) * p.x_stride + is_kc) * 2);
             unsigned char* sbase = smem + it_slot * SB;
             const bool live = it_tile < mtiles;
+            const bool src2 = p.x2_C > 0 && is_kc < p.x2_C;   // this k-step's channels come from the low-resolution source
 #pragma unroll
             for (int j = 0; j < MAXP; ++j) {
                 const int q = lw + j * NL;              // wave-uniform
                 if (q < A_INSTR) {
-                    const unsigned voff = ((pmask[j] >> is_tap) & 1u) ? (pconst[j] + tapoff) : OOB;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(sbase + q * 1024), 16, voff, 0, 0, 0);
+                    const unsigned voff = ((pmask[j] >> is_tap) & 1u) ? ((src2 ? pconst2[j] : pconst[j]) + tapoff) : OOB;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(src2 ? xrs2 : xrs, (lds_void*)(sbase + q * 1024), 16, voff, 0, 0, 0);
                 } else if (q < PIECES) {
                     const unsigned voff = live ? (pconst[j] + (unsigned)(it_kt * BK) * 2u) : OOB;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(sbase + BM * RB + (q - A_INSTR) * 1024), 16, voff, 0, 0, 0);
@@ -269,6 +276,7 @@ bool conv_dma_lc_cfg_valid(const ConvParams& p, int c) {
     if (p.res && p.out_f32) return false;
     const LcCfg& k = kL[c];
     if (k.BK == 64 && ((p.Cin % 64) != 0 || (p.Kpad % 64) != 0)) return false;
+    if (p.x2_C > 0 && (p.ks != 1 || (p.x2_C % k.BK) != 0 || p.x2_bytes >= (1ull << 31))) return false;
     const int cpad = (p.Cout + 31) / 32 * 32;
     if (k.BN >= 2 * cpad) return false;
     // the weight rows of the block must exist (packed weights are padded to 128 rows)

@@ -68,6 +68,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
     const int HoWo = p.Ho * p.Wo;
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t xrs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x2_C > 0 ? p.x2 : p.x), 0, (int)(p.x2_C > 0 ? p.x2_bytes : p.x_bytes), 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
 
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
     }
 
     // ---- issue side -----------------------------------------------------------------------------------------
-    unsigned aconst[A_IPW], amask[A_IPW];
+    unsigned aconst[A_IPW], amask[A_IPW], aconst2[A_IPW];   // aconst2: the same row in the folded-upsample source (p.x2)
     auto set_tile = [&](int mt) {
 #pragma unroll
         for (int j = 0; j < A_IPW; ++j) {
@@ -108,6 +109,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
                 if (p.ks == 1) {
                     base = (unsigned)(m * p.x_stride + p.x_coff) * 2u;
                     mask = 1u;
+                    if (p.x2_C > 0) {
+                        const int b = m / HoWo, r = m - b * HoWo;
+                        const int ho = r / p.Wo, wo = r - ho * p.Wo;
+                        aconst2[j] = (unsigned)(((b * p.x2_H + (ho >> 1)) * p.x2_W + (wo >> 1)) * p.x2_stride + p.x2_coff) * 2u + (unsigned)c * 16u;
+                    }
                 } else {
                     const int b = m / HoWo, r = m - b * HoWo;
                     const int ho = r / p.Wo, wo = r - ho * p.Wo;
@@ -139,10 +145,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
     auto issue_next = [&]() {
         const unsigned tapoff = (unsigned)(((is_ky * p.W + is_kx) * p.x_stride + is_kc) * 2);
         unsigned char* sbase = smem + it_slot * SB;
+        const bool src2 = p.x2_C > 0 && is_kc < p.x2_C;      // this k-step's channels come from the low-resolution source
+        const __amdgpu_buffer_rsrc_t ars = src2 ? xrs2 : xrs;
 #pragma unroll
         for (int j = 0; j < A_IPW; ++j) {
-            const unsigned voff = ((amask[j] >> is_tap) & 1u) ? (aconst[j] + tapoff) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(sbase + (wave * A_IPW + j) * 1024), 16, voff, 0, 0, 0);
+            const unsigned voff = ((amask[j] >> is_tap) & 1u) ? ((src2 ? aconst2[j] : aconst[j]) + tapoff) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, (lds_void*)(sbase + (wave * A_IPW + j) * 1024), 16, voff, 0, 0, 0);
         }
         const bool live = it_tile < mtiles;
         if (!WRES)
@@ -469,6 +477,7 @@ bool conv_dma_p_cfg_valid(const ConvParams& p, int c) {
     if (p.res && p.out_f32) return false;
     const DmaPCfg& k = kP[c];
     if (k.BK == 64 && ((p.Cin % 64) != 0 || (p.Kpad % 64) != 0)) return false;
+    if (p.x2_C > 0 && (p.ks != 1 || (p.x2_C % k.BK) != 0 || p.x2_bytes >= (1ull << 31))) return false;
     const int cpad = (p.Cout + 31) / 32 * 32;
     if (k.BN > 32 && k.BN >= 2 * cpad) return false;
     if (k.BN == 32 && p.Cout > 32) return false;

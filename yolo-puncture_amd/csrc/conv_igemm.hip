@@ -243,6 +243,15 @@ static int conv_tile_choice(const ConvParams& p) {
 // returns 100+c (conv_halo) or 200+c (conv_halo_p)
 static int halo_choice(const ConvParams& p, int dtype) {
     if (dtype != DT_BF16) return -1;
+    if (p.x2_C > 0) {        // folded upsample: only the persistent LDS-DMA families implement the two-source gather
+        auto ok = [&](int c) { return c >= 400 && c < 500 ? conv_dma_lc_cfg_valid(p, c - 400) : (c >= 300 && c < 400 && conv_dma_p_cfg_valid(p, c - 300)); };
+        const int f = conv_dma_forced_cfg();
+        if (ok(f)) return f;
+        if (ok(p.cfg)) return p.cfg;
+        for (int c = 0; c < conv_dma_p_num_cfgs(); ++c)
+            if (conv_dma_p_cfg_valid(p, c)) return 300 + c;
+        return -2;
+    }
     auto valid = [&](int c) {
         if (c >= 500) return conv_halo_s2_cfg_valid(p, c - 500);
         if (c >= 400) return conv_dma_lc_cfg_valid(p, c - 400);
@@ -293,6 +302,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t st) {
 
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st) {
     const int h = halo_choice(p, dtype);
+    if (p.x2_C > 0 && h < 300) return hipErrorInvalidValue;      // (the plan folds an upsample only when such a configuration exists)
     if (h >= 500) return launch_conv_halo_s2(p, h - 500, st);
     if (h >= 400) return launch_conv_dma_lc(p, h - 400, st);
     if (h >= 300) return launch_conv_dma_p(p, h - 300, st);

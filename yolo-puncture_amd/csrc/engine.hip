@@ -339,6 +339,21 @@ static int build_graph(yp_engine& e) {
         }
         if (!other_reader) c.fuse_dw = (int)i;
     }
+    // ---- fold pass: nearest-x2 upsample written into the leading slice of a concat buffer whose only reader is a 1x1 conv ----
+    for (size_t i = 0; i < e.ops.size(); ++i) {
+        const Op& u = e.ops[i];
+        if (u.kind != OP_UPSAMPLE || (u.out.C % 64) != 0) continue;
+        int reader = -1, nread = 0;
+        for (size_t j = 0; j < e.ops.size(); ++j) {
+            const Op& q = e.ops[j];
+            for (const View* v : {&q.in, &q.res})
+                if (v->t == u.out.t && v->coff < u.out.coff + u.out.C && u.out.coff < v->coff + v->C) { reader = (int)j; ++nread; }
+        }
+        if (nread != 1) continue;
+        Op& c = e.ops[reader];
+        if (c.kind != OP_CONV || c.k != 1 || c.s != 1 || c.in.t != u.out.t || c.in.coff != u.out.coff || c.in.C <= u.out.C) continue;
+        c.fold_up = (int)i;
+    }
     // the final 1x1 of each head branch emits fp32 logits
     return YP_OK;
 }
@@ -389,7 +404,17 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel"};
-    for (auto& o : e.ops) { o.fused = false; o.skip = false; }
+    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; }
+    static const bool no_fold = [] { const char* v = std::getenv("YOLOP_NO_FOLD"); return v && *v == '1'; }();   // A/B switch
+    for (auto& o : e.ops) {
+        if (o.kind != OP_CONV || o.fold_up < 0 || e.dtype != DT_BF16 || no_fold) continue;
+        o.folded = true;                                   // tentatively, so that conv_params describes the folded form
+        const ConvParams q = conv_params(e, o);
+        bool any = false;
+        for (int c = 0; c < conv_dma_p_num_cfgs() && !any; ++c) any = conv_dma_p_cfg_valid(q, c);
+        if (any) e.ops[o.fold_up].skip = true;
+        else o.folded = false;
+    }
     for (auto& o : e.ops) {
         if (o.kind == OP_CONV && o.fuse_dw >= 0 && e.dtype == DT_BF16 && e.fuse) {
             const DwPwParams q = dwpw_params(e, o);
@@ -475,6 +500,11 @@ static ConvParams conv_params(const yp_engine& e, const Op& o) {
     p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
     p.up = 1; p.oy = 0; p.ox = 0;
     p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.y_bytes = to.bytes; p.cfg = o.cfg; p.dbg = conv_debug_ablation();
+    if (o.folded) {
+        const Op& u = e.ops[o.fold_up];
+        const TensorDesc& t2 = e.tensors[u.in.t];
+        p.x2 = t2.ptr; p.x2_bytes = t2.bytes; p.x2_stride = t2.C; p.x2_coff = u.in.coff; p.x2_C = u.out.C; p.x2_H = t2.H; p.x2_W = t2.W;
+    }
     return p;
 }
 
@@ -618,7 +648,7 @@ static int autotune(yp_engine& e) {
         float best = 1e30f;
         int bestc = -1;
         for (int c = 0; c < conv_dma_num_cfgs(); ++c) {
-            if (!conv_dma_cfg_valid(p, c)) continue;
+            if (p.x2_C > 0 || !conv_dma_cfg_valid(p, c)) continue;          // (the one-tile-per-workgroup family has no folded-upsample gather)
             o.cfg = c;
             float tmin;
             hipError_t err = time_cfg(o, tmin);
@@ -734,6 +764,7 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     rd.clear(); wr.clear();
     if (o.skip) return;
     if (o.fused) rd.push_back(e.ops[o.fuse_dw].in);
+    if (o.folded) rd.push_back(e.ops[o.fold_up].in);
     else if (o.in.t >= 0) rd.push_back(o.in);
     if (o.res.t >= 0) rd.push_back(o.res);
     if (o.out.t >= 0) wr.push_back(o.out);
