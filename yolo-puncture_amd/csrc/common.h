@@ -71,6 +71,8 @@ struct Op {
     int fuse_dw = -1;             // OP_CONV 1x1: index of the depthwise 3x3 op feeding it that can be fused in (graph pass)
     bool fused = false;           // plan decision: this conv runs as the fused dw->pw kernel
     bool skip = false;            // plan decision: this op's work is done by a fused consumer
+    int fuse_pre = -1;            // OP_CONV 1x1: index of the 3x3 stride-2 conv feeding it that can run as the first stage of one kernel
+    bool fused2 = false;          // plan decision: this 1x1 runs as the second stage of conv_halo_s2's PW2 form
     int fold_up = -1;             // OP_CONV 1x1 on a [upsampled | skip] concat: index of the nearest-x2 upsample op it can absorb
     bool folded = false;          // plan decision: the upsample is folded into this conv's input gather
     int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
@@ -96,6 +98,9 @@ struct ConvParams {
     // folded nearest-x2 upsample (1x1 convs on a [upsampled | skip] concat): input channels [0, x2_C) are read from the
     // low-resolution tensor x2 at pixel (ho >> 1, wo >> 1) instead of from x; channels >= x2_C come from x as usual
     const void* x2; size_t x2_bytes; int x2_stride, x2_coff, x2_C, x2_H, x2_W;
+    // fused trailing 1x1 (conv_halo_s2 PW2 form): y = act2(W2 . act(conv(x)) + bias2); Cout is then the intermediate width,
+    // y / y_stride / y_coff / y_bytes describe the FINAL output of C2 channels
+    const void* w2; const float* bias2; int C2, act2, Kpad2; size_t w2_bytes;
 };
 
 struct DwParams {
@@ -170,6 +175,8 @@ int conv_halo_s2_num_cfgs();
 bool conv_halo_s2_cfg_valid(const ConvParams& p, int c);
 const char* conv_halo_s2_kernel_name(int c);
 hipError_t launch_conv_halo_s2(const ConvParams& p, int c, hipStream_t st);
+int conv_halo_s2_pw_cfg(const ConvParams& p);          // configuration for the fused trailing-1x1 form, or -1
+const char* conv_halo_s2_pw_kernel_name(int c);
 int conv_dma_lc_num_cfgs();
 bool conv_dma_lc_cfg_valid(const ConvParams& p, int c);
 const char* conv_dma_lc_kernel_name(int c);

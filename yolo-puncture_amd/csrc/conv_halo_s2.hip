@@ -26,7 +26,7 @@ template <int N> __device__ __forceinline__ void wait_vs2() {
 }
 __device__ __forceinline__ int sswz(int row) { return ((row >> 2) & 1) << 1; }
 
-template <int FM, int FN, int WGM, int WGN, int NSH, bool HAS_RES, bool OUT_F32>
+template <int FM, int FN, int WGM, int WGN, int NSH, bool HAS_RES, bool OUT_F32, bool PW2>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_s2_kernel(const ConvParams p, const int tiles_h, const int tiles_w,
                                                                     const int ntiles, const int G) {
     constexpr int NW = WGM * WGN;
@@ -87,6 +87,27 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_s2_kernel(const Conv
             const int tap = q % 9, ch = q / 9;
             const unsigned voff = (unsigned)(((n0 + n) * p.Kpad + tap * p.Cin + ch * 32 + c8 * 8) * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(Wres + ii * 1024), 16, voff, 0, 0, 0);
+        }
+    }
+
+    // ---- PW2: the trailing 1x1's weights [C2 = BN][BN] (128-B rows, 8-slot swizzle) stay in LDS behind the 3x3 weights ------
+    unsigned char* const W2s = Wres + (size_t)9 * nchunk * BN * 64;
+    float bias2[FN][4];
+    if (PW2) {
+        static_assert(!PW2 || BN == 64, "the fused trailing 1x1 is written for a 64-wide intermediate and output");
+        const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (int)p.w2_bytes, 0x00020000);
+        for (int ii = wave; ii < BN * 8 / 64; ii += NW) {          // BN rows x 8 chunks of 16 B
+            const int s = ii * 64 + lane;
+            const int row = s >> 3, pc = s & 7;
+            const int c8 = pc ^ ((row >> 1) & 7);
+            const unsigned voff = (unsigned)((row * p.Kpad2 + c8 * 8) * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(w2rs, (lds_void*)(W2s + ii * 1024), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int co = wn * (FN * 16) + a * 16 + fc * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bias2[a][r] = (co + r < p.C2) ? p.bias2[co + r] : 0.f;
         }
     }
 
@@ -194,6 +215,49 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_s2_kernel(const Conv
             rd_slot = (rd_slot + 1 == NSH) ? 0 : rd_slot + 1;
         }
 
+        if (PW2) {
+            // the tile's intermediate (bias + SiLU, bf16 - exactly the tensor the unfused graph would store) goes through the
+            // halo slot this tile just finished with (free until the ring refills it after the next iteration's barrier)
+            // and is multiplied by the resident 64x64 weights; acc is then the trailing 1x1's accumulator
+            unsigned char* tb = Hs + ((rd_slot == 0) ? NSH - 1 : rd_slot - 1) * HB;
+            __builtin_amdgcn_s_barrier();                     // every wave is done reading that slot
+#pragma unroll
+            for (int r = 0; r < FM; ++r) {
+                const int px = (wm * FM + r) * 16 + fr;
+#pragma unroll
+                for (int a = 0; a < FN; ++a) {
+                    const int co = wn * (FN * 16) + a * 16 + fc * 4;
+                    __attribute__((aligned(8))) __bf16 o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(p.act == ACT_SILU ? silu_s2(acc[a][r][i]) : acc[a][r][i]);
+                    *(uint2*)(tb + px * 128 + (((co >> 3) ^ ((px >> 1) & 7)) * 16) + (co & 7) * 2) = *(const uint2*)o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int a = 0; a < FN; ++a)
+#pragma unroll
+                for (int r = 0; r < FM; ++r) acc[a][r] = f32x4{bias2[a][0], bias2[a][1], bias2[a][2], bias2[a][3]};
+#pragma unroll
+            for (int ss = 0; ss < 2; ++ss) {
+                bf16x8 w2f[FN], t2f[FM];
+#pragma unroll
+                for (int a = 0; a < FN; ++a) {
+                    const int rw = wn * (FN * 16) + a * 16 + fr;
+                    w2f[a] = *(const bf16x8*)(W2s + rw * 128 + (((ss * 4 + fc) ^ ((rw >> 1) & 7)) * 16));
+                }
+#pragma unroll
+                for (int r = 0; r < FM; ++r) {
+                    const int px = (wm * FM + r) * 16 + fr;
+                    t2f[r] = *(const bf16x8*)(tb + px * 128 + (((ss * 4 + fc) ^ ((px >> 1) & 7)) * 16));
+                }
+#pragma unroll
+                for (int a = 0; a < FN; ++a)
+#pragma unroll
+                    for (int r = 0; r < FM; ++r) acc[a][r] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[a], t2f[r], acc[a][r], 0, 0, 0);
+            }
+        }
         // ---- epilogue of `tile`: exactly S buffer stores per wave ---------------------------------------------------------
         {
             int t = tile;
@@ -226,12 +290,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_s2_kernel(const Conv
 #pragma unroll
                 for (int a = 0; a < FN; ++a) {
                     const int co = n0 + wn * (FN * 16) + a * 16 + fc * 4;
-                    const bool ok = pix_ok && (co < p.Cout);
+                    const bool ok = pix_ok && (co < (PW2 ? p.C2 : p.Cout));
                     float v[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         float tt = acc[a][r][i];
-                        if (p.act == ACT_SILU) tt = silu_s2(tt);
+                        if ((PW2 ? p.act2 : p.act) == ACT_SILU) tt = silu_s2(tt);
                         v[i] = tt;
                     }
                     if (HAS_RES) {
@@ -268,10 +332,10 @@ constexpr int kNumS2 = (int)(sizeof(kS2) / sizeof(kS2[0]));
 int conv_halo_s2_num_cfgs() { return kNumS2; }
 const char* conv_halo_s2_kernel_name(int c) { return kS2[c].name; }
 
-static size_t halo_s2_lds(const HaloS2Cfg& k, int Cin) {
+static size_t halo_s2_lds(const HaloS2Cfg& k, int Cin, bool pw2 = false) {
     const int TH = k.WGM * k.FM, BN = k.WGN * k.FN * 16;
     const int HP = (2 * TH + 1) * 33, H_INSTR = (HP * 4 + 63) / 64;
-    return (size_t)3 * H_INSTR * 1024 + 1024 + (size_t)9 * (Cin / 32) * BN * 64;
+    return (size_t)3 * H_INSTR * 1024 + 1024 + (size_t)9 * (Cin / 32) * BN * 64 + (pw2 ? (size_t)BN * 128 : 0);
 }
 
 bool conv_halo_s2_cfg_valid(const ConvParams& p, int c) {
@@ -291,10 +355,10 @@ bool conv_halo_s2_cfg_valid(const ConvParams& p, int c) {
     return true;
 }
 
-template <int FM, int FN, int WGM, int WGN, bool HAS_RES, bool OUT_F32>
+template <int FM, int FN, int WGM, int WGN, bool HAS_RES, bool OUT_F32, bool PW2 = false>
 static hipError_t launch_halo_s2_var(const ConvParams& p, const HaloS2Cfg& k, hipStream_t st) {
     constexpr int TH = WGM * FM, BN = WGN * FN * 16;
-    const size_t sh = halo_s2_lds(k, p.Cin);
+    const size_t sh = halo_s2_lds(k, p.Cin, PW2);
     const int B = p.M / (p.Ho * p.Wo);
     const int tiles_h = (p.Ho + TH - 1) / TH, tiles_w = (p.Wo + 15) / 16, ntiles = (p.Cout + BN - 1) / BN;
     const int num_tiles = B * tiles_h * tiles_w;
@@ -302,7 +366,7 @@ static hipError_t launch_halo_s2_var(const ConvParams& p, const HaloS2Cfg& k, hi
     int G = (256 * per_cu) / ntiles;
     if (G < 1) G = 1;
     if (G > num_tiles) G = num_tiles;
-    auto kern = conv_halo_s2_kernel<FM, FN, WGM, WGN, 3, HAS_RES, OUT_F32>;
+    auto kern = conv_halo_s2_kernel<FM, FN, WGM, WGN, 3, HAS_RES, OUT_F32, PW2>;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -320,8 +384,30 @@ static hipError_t launch_halo_s2_one(const ConvParams& p, const HaloS2Cfg& k, hi
     return launch_halo_s2_var<FM, FN, WGM, WGN, false, false>(p, k, st);
 }
 
+// ---- fused trailing 1x1 ------------------------------------------------------------------------------------------------
+// valid when the 3x3 s2 conv and the 1x1 behind it are both 64 wide (model.1 -> model.2.cv1 of v10-S), nothing carries a residual,
+// the intermediate has no other reader (the graph pass checks that), and LDS holds both weight sets beside the halo ring
+int conv_halo_s2_pw_cfg(const ConvParams& p) {
+    if (p.w2 == nullptr && p.C2 == 0) return -1;
+    if (p.Cout != 64 || p.C2 != 64 || p.Kpad2 != 64 || p.res || p.out_f32) return -1;
+    for (int c : {0, 1}) {
+        ConvParams q = p;
+        q.Cout = p.C2;                                          // the store-side checks of the plain form apply to the final view
+        if (!conv_halo_s2_cfg_valid(q, c)) continue;
+        if (halo_s2_lds(kS2[c], p.Cin, true) > 160 * 1024) continue;
+        return c;
+    }
+    return -1;
+}
+const char* conv_halo_s2_pw_kernel_name(int c) { return c == 0 ? "conv_halo_s2_kernel<2,2,4,2,3,false,false,true>" : "conv_halo_s2_kernel<1,2,4,2,3,false,false,true>"; }
+
 hipError_t launch_conv_halo_s2(const ConvParams& p, int c, hipStream_t st) {
     const HaloS2Cfg& k = kS2[c];
+    if (p.C2 > 0) {
+        if (c == 0) return launch_halo_s2_var<2, 2, 4, 2, false, false, true>(p, k, st);
+        if (c == 1) return launch_halo_s2_var<1, 2, 4, 2, false, false, true>(p, k, st);
+        return hipErrorInvalidValue;
+    }
     switch (c) {
         case 0: return launch_halo_s2_one<2, 2, 4, 2>(p, k, st);
         case 1: return launch_halo_s2_one<1, 2, 4, 2>(p, k, st);

@@ -354,6 +354,22 @@ static int build_graph(yp_engine& e) {
         if (c.kind != OP_CONV || c.k != 1 || c.s != 1 || c.in.t != u.out.t || c.in.coff != u.out.coff || c.in.C <= u.out.C) continue;
         c.fold_up = (int)i;
     }
+    // ---- 3x3 stride-2 conv whose only consumer is the next op, a 1x1 conv: candidates for conv_halo_s2's fused trailing 1x1 -----
+    for (size_t i = 0; i + 1 < e.ops.size(); ++i) {
+        const Op& a = e.ops[i];
+        Op& c = e.ops[i + 1];
+        if (a.kind != OP_CONV || a.k != 3 || a.s != 2 || a.res.t >= 0) continue;
+        if (c.kind != OP_CONV || c.k != 1 || c.s != 1 || c.res.t >= 0 || c.fold_up >= 0 || c.fuse_dw >= 0) continue;
+        if (c.in.t != a.out.t || c.in.coff != a.out.coff || c.in.C != a.out.C) continue;
+        bool other_reader = false;
+        for (size_t j = 0; j < e.ops.size(); ++j) {
+            if (j == i + 1) continue;
+            const Op& q = e.ops[j];
+            for (const View* v : {&q.in, &q.res})
+                if (v->t == a.out.t && v->coff < a.out.coff + a.out.C && a.out.coff < v->coff + v->C) other_reader = true;
+        }
+        if (!other_reader) c.fuse_pre = (int)i;
+    }
     // the final 1x1 of each head branch emits fp32 logits
     return YP_OK;
 }
@@ -404,7 +420,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel"};
-    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; }
+    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; }
     static const bool no_fold = [] { const char* v = std::getenv("YOLOP_NO_FOLD"); return v && *v == '1'; }();   // A/B switch
     for (auto& o : e.ops) {
         if (o.kind != OP_CONV || o.fold_up < 0 || e.dtype != DT_BF16 || no_fold) continue;
@@ -416,6 +432,12 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         else o.folded = false;
     }
     for (auto& o : e.ops) {
+        if (o.kind == OP_CONV && o.fuse_pre >= 0 && e.dtype == DT_BF16 && e.fuse) {
+            o.fused2 = true;
+            const int c = conv_halo_s2_pw_cfg(conv_params(e, o));
+            if (c >= 0) { e.ops[o.fuse_pre].skip = true; o.cfg = 500 + c; o.kernel = conv_halo_s2_pw_kernel_name(c); continue; }
+            o.fused2 = false;
+        }
         if (o.kind == OP_CONV && o.fuse_dw >= 0 && e.dtype == DT_BF16 && e.fuse) {
             const DwPwParams q = dwpw_params(e, o);
             if (conv_dwpw_valid(q)) { o.fused = true; e.ops[o.fuse_dw].skip = true; o.kernel = conv_dwpw_kernel_name(q); continue; }
@@ -489,6 +511,17 @@ static int allocate_plan(yp_engine& e) {
 struct RunArgs { const uint8_t* in; float* det; int32_t* idx; float* coeff; };
 
 static ConvParams conv_params(const yp_engine& e, const Op& o) {
+    if (o.fused2) {            // the 3x3 s2 producer's parameters with this 1x1 as the trailing stage
+        const Op& a = e.ops[o.fuse_pre];
+        Op a1 = a;
+        a1.cfg = o.cfg;
+        ConvParams p = conv_params(e, a1);
+        const WeightDesc& w2 = e.weights[o.widx];
+        const TensorDesc& to = e.tensors[o.out.t];
+        p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.y_bytes = to.bytes;
+        p.w2 = w2.d_w; p.bias2 = w2.d_b; p.C2 = o.out.C; p.act2 = o.act; p.Kpad2 = w2.Kpad; p.w2_bytes = w2.mat_bytes;
+        return p;
+    }
     const WeightDesc& w = e.weights[o.widx];
     const TensorDesc &ti = e.tensors[o.in.t], &to = e.tensors[o.out.t];
     ConvParams p{};
@@ -522,6 +555,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
         }
         case OP_CONV:
             if (o.fused) return launch_conv_dwpw(dwpw_params(e, o), st);
+            if (o.fused2) { const ConvParams q = conv_params(e, o); return launch_conv_halo_s2(q, o.cfg - 500, st); }
             return launch_conv(conv_params(e, o), e.dtype, st);
         case OP_CONVT: {
             const WeightDesc& w = e.weights[o.widx];
@@ -639,7 +673,7 @@ static int autotune(yp_engine& e) {
     };
     for (Op& o : e.ops) {
         if (o.kind != OP_CONV && o.kind != OP_CONVT) continue;
-        if (o.fused) continue;
+        if (o.fused || o.fused2) continue;
         ConvParams p{};
         if (o.kind == OP_CONV) p = conv_params(e, o);
         else { p.Cin = o.in.C; p.Cout = o.out.C; p.ks = 1; p.Kpad = e.weights[o.widx].Kpad; p.M = e.pB * e.tensors[o.in.t].H * e.tensors[o.in.t].W;
@@ -708,6 +742,7 @@ static bool load_tune_cache(yp_engine& e) {
     for (Op& o : e.ops)
         if (o.kind == OP_CONV || o.kind == OP_CONVT) {
             o.cfg = m[o.name];
+            if (o.fused2) { o.cfg = 500 + conv_halo_s2_pw_cfg(conv_params(e, o)); continue; }
             if (o.kind == OP_CONV && !o.fused) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);   // a fused dw->pw op keeps its own symbol
         }
     return true;
@@ -764,8 +799,9 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     rd.clear(); wr.clear();
     if (o.skip) return;
     if (o.fused) rd.push_back(e.ops[o.fuse_dw].in);
-    if (o.folded) rd.push_back(e.ops[o.fold_up].in);
+    else if (o.fused2) rd.push_back(e.ops[o.fuse_pre].in);
     else if (o.in.t >= 0) rd.push_back(o.in);
+    if (o.folded) rd.push_back(e.ops[o.fold_up].in);      // (besides the concat buffer, whose skip part it still reads)
     if (o.res.t >= 0) rd.push_back(o.res);
     if (o.out.t >= 0) wr.push_back(o.out);
     if (o.kind == OP_HEAD)
