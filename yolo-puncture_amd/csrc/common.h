@@ -19,6 +19,7 @@ enum OpKind {
     OP_ATTN = 5,      // PSA attention core: softmax(q^T k * scale) applied to v
     OP_HEAD = 6,      // DFL decode + sigmoid + two-stage top-k
     OP_CONVT = 7,     // ConvTranspose2d k2 s2 (Proto) = 4 strided 1x1 GEMMs
+    OP_AMAX = 9,      // per-level class-max of the head (sigmoid(max_c logit)) - runs on the level's class lane
     OP_POOL3 = 8,     // SPPF: three chained 5x5 max-pools in one launch (out = first pooled slice, 3*C channels written)
 };
 
@@ -64,6 +65,7 @@ struct Op {
     int gs = 0, gstride = 0;      // depthwise input channel gather: in_ch = coff + (c/gs)*gstride + c%gs (gs=0: identity)
     int nh = 0, kd = 0, hd = 0;   // attention
     View box[3], cls[3], cf[3];   // head inputs per level
+    View amax[3];                 // head: per-level anchor-max keys (written by the OP_AMAX ops)
     int nlev = 0;
     double flops = 0, bytes = 0;  // algorithmic (filled by the plan)
     std::string kernel;           // device kernel symbol this op launches (filled by the plan)
@@ -148,6 +150,8 @@ struct HeadParams {
     int B, nc, max_det, A;
     float* det; int32_t* idx; float* coeff;   // user outputs
     void* scratch;                            // device scratch, head_scratch_bytes(B, A)
+    const unsigned* mk[3];                    // per-level anchor-max keys [B][HW_l] (bits of sigmoid(max_c logit)); when set, the
+                                              // class-max pass already ran (OP_AMAX) and `scratch` is not used
 };
 
 // launches (implemented in the .hip files); dtype selects the template instance
@@ -201,6 +205,7 @@ hipError_t launch_letterbox(const uint8_t* src, int h0, int w0, uint8_t* dst, in
                             int left, int pad, hipStream_t st);
 size_t head_scratch_bytes(int B, int A);
 hipError_t head_read_clocks(unsigned long long* out8);
+hipError_t launch_anchor_max_level(const float* cls, int B, int HW, int nc, unsigned* out, hipStream_t st);
 
 struct DwPwParams {                              // fused depthwise 3x3 s1 -> pointwise 1x1 (conv_dwpw.hip)
     const void* x; int x_stride, x_coff; int B, H, W, C; size_t x_bytes;

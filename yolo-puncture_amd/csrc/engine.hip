@@ -290,6 +290,14 @@ static int build_graph(yp_engine& e) {
         B.dwconv(pc + ".1.0", B.full(k1), B.full(k2), 3, 1, ACT_SILU);
         B.conv(pc + ".1.1", B.full(k2), B.full(k3), 1, 1, ACT_SILU);
         B.conv(pc + ".2", B.full(k3), B.full(k4), 1, 1, ACT_NONE);
+        {   // class-max keys of this level, produced on the class lane right behind the logits
+            const int am = B.tensor("model.23.amax." + L, 1, sd, true);
+            Op o;
+            o.lane = B.lane;
+            o.kind = OP_AMAX; o.name = "model.23.amax." + L; o.in = B.full(k4); o.out = B.full(am);
+            e.ops.push_back(o);
+            head.amax[l] = B.full(am);
+        }
         head.box[l] = B.full(b2);
         head.cls[l] = B.full(k4);
         if (e.desc.task == YP_TASK_SEGMENT) {
@@ -412,14 +420,14 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
             const double Nn = (double)ti.H * ti.W;
             o.flops = 2.0 * B * o.nh * Nn * Nn * (o.kd + o.hd);
         } else if (o.kind == OP_HEAD) {
-            o.bytes = 0;
-            for (int l = 0; l < 3; ++l) o.bytes += vbytes(o.cls[l]);
-            o.bytes += (double)B * e.desc.max_det * (6 + 1) * 4;
+            o.bytes = 0;                       // class-max keys + the winners' class / box rows + the outputs
+            for (int l = 0; l < 3; ++l) o.bytes += (o.amax[l].t >= 0) ? vbytes(o.amax[l]) : vbytes(o.cls[l]);
+            o.bytes += (double)B * e.desc.max_det * (e.desc.nc + 64 + 6 + 1) * 4;
         }
     }
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
     for (auto& o : e.ops) o.cfg = -1;
-    static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel"};
+    static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel", "anchor_max_level_kernel"};
     for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; }
     static const bool no_fold = [] { const char* v = std::getenv("YOLOP_NO_FOLD"); return v && *v == '1'; }();   // A/B switch
     for (auto& o : e.ops) {
@@ -622,6 +630,10 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             p.B = B; p.N = ti.H * ti.W; p.nh = o.nh; p.kd = o.kd; p.hd = o.hd; p.scale = 1.0f / std::sqrt((float)o.kd);
             return launch_attention(p, e.dtype, st);
         }
+        case OP_AMAX: {
+            const TensorDesc &ti = T(o.in), &to = T(o.out);
+            return launch_anchor_max_level((const float*)ti.ptr, B, ti.H * ti.W, o.in.C, (unsigned*)to.ptr, st);
+        }
         case OP_HEAD: {
             HeadParams p{};
             p.nlev = 3; p.A = 0;
@@ -633,6 +645,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             }
             p.B = B; p.nc = e.desc.nc; p.max_det = e.desc.max_det;
             p.det = a.det; p.idx = a.idx; p.coeff = (o.cf[0].t >= 0) ? a.coeff : nullptr; p.scratch = e.head_ws;
+            for (int l = 0; l < 3; ++l) p.mk[l] = (o.amax[l].t >= 0) ? (const unsigned*)T(o.amax[l]).ptr : nullptr;
             return launch_head(p, st);
         }
     }
@@ -809,6 +822,7 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
             if (o.box[l].t >= 0) rd.push_back(o.box[l]);
             if (o.cls[l].t >= 0) rd.push_back(o.cls[l]);
             if (o.cf[l].t >= 0) rd.push_back(o.cf[l]);
+            if (o.amax[l].t >= 0) rd.push_back(o.amax[l]);
         }
 }
 

@@ -88,6 +88,41 @@ __global__ __launch_bounds__(256) void anchor_max4_kernel(const HeadParams p, un
     if (a < na && sub == 0) mkey[(size_t)b * p.A + abase + a0 + a] = __float_as_uint(sigmoidf_(mx));
 }
 
+// one level, one launch (OP_AMAX): the class-max pass of a level runs on that level's class lane as soon as its logits exist,
+// so only the select kernel is left on the tail of the graph. Same arithmetic as anchor_max4_kernel.
+__global__ __launch_bounds__(256) void anchor_max_level_kernel(const float* __restrict__ cls, const int B, const int HW, const int nc,
+                                                               unsigned* __restrict__ out) {
+    __shared__ float part[64 * 64];
+    const int bpi = (HW + 63) / 64;
+    const int b = blockIdx.x / bpi, a0 = (blockIdx.x - b * bpi) * 64;
+    const int na = min(64, HW - a0);
+    const int a = threadIdx.x >> 2, sub = threadIdx.x & 3;
+    float mx = -INFINITY;
+    if ((nc & 3) == 0 && nc <= 256) {
+        const int q = nc >> 2;
+        const float4* src = (const float4*)(cls + ((size_t)b * HW + a0) * nc);
+        const int n4 = na * q;
+        for (int i = threadIdx.x; i < n4; i += 256) {
+            const float4 v = src[i];
+            part[i] = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+        }
+        __syncthreads();
+        if (a < na)
+            for (int j = sub; j < q; j += 4) mx = fmaxf(mx, part[a * q + j]);
+    } else if (a < na) {
+        const float* cp = cls + ((size_t)b * HW + a0 + a) * nc;
+        for (int c = sub; c < nc; c += 4) mx = fmaxf(mx, cp[c]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
+    if (a < na && sub == 0) out[(size_t)b * HW + a0 + a] = __float_as_uint(sigmoidf_(mx));
+}
+
+hipError_t launch_anchor_max_level(const float* cls, int B, int HW, int nc, unsigned* out, hipStream_t st) {
+    hipLaunchKernelGGL(anchor_max_level_kernel, dim3((unsigned)(B * ((HW + 63) / 64))), dim3(256), 0, st, cls, B, HW, nc, out);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // LDS helpers of kernel 2 (all HT threads participate)
 // ---------------------------------------------------------------------------------------------------------------
@@ -172,6 +207,7 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
     unsigned long long* carry = best + 512;         // [512] running best-k between stage-2 rounds
     unsigned long long* tmp = carry + 512;          // [512] unsorted survivors of a select
     int* sel = (int*)(tmp + 512);                   // [MAXK] stage-1 winners (anchor ids, rank order)
+    const float** selrow = (const float**)(sel + MAXK);   // [MAXK] their class-logit rows
     __shared__ SelectShared S;
     __shared__ unsigned nfill;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -180,17 +216,40 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
 
     HEAD_STAMP(0);
     // ---- stage 1: top-k anchors by (max score desc, anchor asc) ---------------------------------------------------------
-    for (int a = tid; a < A; a += HT) keys[a] = ((unsigned long long)mkey[(size_t)b * A + a] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
+    if (p.mk[0]) {
+        int off = 0;
+        for (int l = 0; l < 3; ++l) {                      // level by level: coalesced, no per-key level search
+            const int HWl = p.hw[l][0] * p.hw[l][1];
+            const unsigned* src = p.mk[l] + (size_t)b * HWl;
+            for (int a = tid; a < HWl; a += HT)
+                keys[off + a] = ((unsigned long long)src[a] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(off + a));
+            off += HWl;
+        }
+    } else {
+        for (int a = tid; a < A; a += HT)
+            keys[a] = ((unsigned long long)mkey[(size_t)b * A + a] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
+    }
     __syncthreads();
     HEAD_STAMP(1);
     select_topk_sorted(keys, A, k, best, tmp, S);
     HEAD_STAMP(2);
-    for (int r = tid; r < k; r += HT) sel[r] = (int)(0xFFFFFFFFu - (unsigned)(best[r] & 0xFFFFFFFFull));
+    for (int r = tid; r < k; r += HT) {
+        const int a = (int)(0xFFFFFFFFu - (unsigned)(best[r] & 0xFFFFFFFFull));
+        sel[r] = a;
+        int l, loc, HWl;
+        locate(a, l, loc, HWl);
+        selrow[r] = p.cls[l] + ((size_t)b * HWl + loc) * p.nc;           // class-logit row of the r-th selected anchor
+    }
     const unsigned thr_bits = (unsigned)(best[k - 1] >> 32);   // every selected anchor has a class with score >= this
     __syncthreads();
 
     // ---- stage 2: top-k of the k*nc (rank, class) candidates. A candidate below the stage-1 threshold can never be
     //      in the result (>= k candidates reach it), so only survivors enter LDS; rounds bound the LDS use exactly. ----
+    // sigmoid is monotone, so a candidate can reach the stage-1 threshold only if its logit reaches logit(thr) - a margin that
+    // covers the rounding of both evaluations (1e-3 in logit space moves a score by >= 2.5e-4 * s * (1 - s), far above 1 ulp
+    // unless the score saturates; above 0.999 the filter is switched off)
+    const float thr_f = __uint_as_float(thr_bits);
+    const float lthr = (thr_f > 0.f && thr_f < 0.999f) ? (logf(thr_f / (1.0f - thr_f)) - 1e-3f) : -INFINITY;
     const int total = k * p.nc;
     int have = 0;                       // keys carried from earlier rounds (sorted, in carry[0..have))
     for (int done = 0; done < total;) {
@@ -204,24 +263,22 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
             if (chunk <= 0) break;
             const int take = min(chunk, total - f0);
             constexpr int U = 24;                                  // independent gathers in flight per thread
+            const int qs = HT / p.nc, rs = HT - qs * p.nc;         // (r, c) of candidate f advance by (qs, rs) per HT candidates
             for (int i0 = tid; i0 < take; i0 += U * HT) {
                 float lg[U];
+                int r = (f0 + i0) / p.nc, c = (f0 + i0) - r * p.nc;
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = i0 + u * HT;
                     lg[u] = -INFINITY;
-                    if (i < take) {
-                        const int f = f0 + i;
-                        const int r = f / p.nc, c = f - r * p.nc;
-                        int l, loc, HWl;
-                        locate(sel[r], l, loc, HWl);
-                        lg[u] = p.cls[l][((size_t)b * HWl + loc) * p.nc + c];
-                    }
+                    if (i < take) lg[u] = selrow[r][c];
+                    c += rs; r += qs;
+                    if (c >= p.nc) { c -= p.nc; ++r; }
                 }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int i = i0 + u * HT;
-                    if (i < take) {
+                    if (i < take && lg[u] >= lthr) {                  // (cheap necessary condition first: most candidates stop here)
                         const float s = sigmoidf_(lg[u]);
                         if (__float_as_uint(s) >= thr_bits) keys[atomicAdd(&nfill, 1u)] = make_key(s, (unsigned)(f0 + i));
                     }
@@ -299,8 +356,8 @@ hipError_t head_read_clocks(unsigned long long* out8) { return hipMemcpyFromSymb
 size_t head_scratch_bytes(int B, int A) { return (size_t)B * A * sizeof(unsigned); }
 
 hipError_t launch_head(const HeadParams& p, hipStream_t st) {
-    if (p.A > CAP || p.max_det > MAXK || p.scratch == nullptr) return hipErrorInvalidValue;
-    const size_t sh = (size_t)(CAP + 1536) * 8 + MAXK * 4;
+    if (p.A > CAP || p.max_det > MAXK || (p.scratch == nullptr && p.mk[0] == nullptr)) return hipErrorInvalidValue;
+    const size_t sh = (size_t)(CAP + 1536) * 8 + MAXK * 4 + MAXK * 8;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)head_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
@@ -308,7 +365,9 @@ hipError_t launch_head(const HeadParams& p, hipStream_t st) {
         attr_set = true;
     }
     unsigned* mkey = (unsigned*)p.scratch;
-    if ((p.nc & 3) == 0 && p.nc <= 256) {
+    if (p.mk[0]) {
+        // class-max keys were produced per level by OP_AMAX
+    } else if ((p.nc & 3) == 0 && p.nc <= 256) {
         const int nb0 = (p.hw[0][0] * p.hw[0][1] + 63) / 64, nb1 = (p.hw[1][0] * p.hw[1][1] + 63) / 64, nb2 = (p.hw[2][0] * p.hw[2][1] + 63) / 64;
         const int bpi = nb0 + nb1 + nb2;
         hipLaunchKernelGGL(anchor_max4_kernel, dim3((unsigned)(p.B * bpi)), dim3(256), 0, st, p, mkey, bpi, nb0, nb1);

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_HERE, "libyolop.so")
 
 YP_BF16, YP_F32 = 0, 1
 TASK_DETECT, TASK_SEGMENT = 0, 1
-OP_KINDS = {0: "stem", 1: "conv", 2: "dwconv", 3: "pool5", 4: "upsample", 5: "attn", 6: "head", 7: "convT", 8: "pool3"}
+OP_KINDS = {0: "stem", 1: "conv", 2: "dwconv", 3: "pool5", 4: "upsample", 5: "attn", 6: "head", 7: "convT", 8: "pool3", 9: "amax"}
 
 
 class ModelDesc(C.Structure):
