@@ -75,6 +75,8 @@ struct Op {
     bool skip = false;            // plan decision: this op's work is done by a fused consumer
     int fuse_pre = -1;            // OP_CONV 1x1: index of the 3x3 stride-2 conv feeding it that can run as the first stage of one kernel
     bool fused2 = false;          // plan decision: this 1x1 runs as the second stage of conv_halo_s2's PW2 form
+    int stem_op = -1;             // fused2 whose first stage reads the stem's output: index of the stem op
+    bool fused3 = false;          // plan decision: stem -> 3x3 s2 -> this 1x1 run as frontend_kernel
     int fold_up = -1;             // OP_CONV 1x1 on a [upsampled | skip] concat: index of the nearest-x2 upsample op it can absorb
     bool folded = false;          // plan decision: the upsample is folded into this conv's input gather
     int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
@@ -124,6 +126,17 @@ struct StemParams {
     void* y; int y_stride, y_coff; int Ho, Wo, C0; int B;
     int act;
 };
+
+// fused front end (frontend.hip): stem -> 3x3 s2 conv -> 1x1 conv
+struct FrontParams {
+    const uint8_t* img; int imgH, imgW, B;                               // [B,imgH,imgW,3] BGR u8
+    const void* w0; const float* bias0; int act0, C0; int H1, W1;         // stem: bf16 [C0][32], output grid H1 x W1
+    const void* w1; const float* bias1; int act1, C1, Kpad1; size_t w1_bytes;   // 3x3 s2: packed [C1^][9*C0]
+    const void* w2; const float* bias2; int act2, C2, Kpad2; size_t w2_bytes;   // 1x1:    packed [C2^][C1]
+    void* y; int y_stride, y_coff; size_t y_bytes; int Ho, Wo;           // final output view (Ho x Wo = H1/2 x W1/2)
+};
+bool frontend_valid(const FrontParams& p);
+hipError_t launch_frontend(const FrontParams& p, hipStream_t st);
 
 struct PoolParams {
     const void* x; int x_stride, x_coff;

@@ -387,6 +387,7 @@ static int build_graph(yp_engine& e) {
 // ---------------------------------------------------------------------------------------------------------
 static ConvParams conv_params(const yp_engine& e, const Op& o);
 static DwPwParams dwpw_params(const yp_engine& e, const Op& c);
+static FrontParams front_params(const yp_engine& e, const Op& o, const uint8_t* img);
 static size_t tensor_elem_bytes(const yp_engine& e, const TensorDesc& t) { return (t.f32 || e.dtype == DT_F32) ? 4 : 2; }
 
 static int make_plan(yp_engine& e, int B, int H, int W) {
@@ -428,7 +429,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel", "anchor_max_level_kernel"};
-    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; }
+    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; }
     static const bool no_fold = [] { const char* v = std::getenv("YOLOP_NO_FOLD"); return v && *v == '1'; }();   // A/B switch
     for (auto& o : e.ops) {
         if (o.kind != OP_CONV || o.fold_up < 0 || e.dtype != DT_BF16 || no_fold) continue;
@@ -443,7 +444,22 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         if (o.kind == OP_CONV && o.fuse_pre >= 0 && e.dtype == DT_BF16 && e.fuse) {
             o.fused2 = true;
             const int c = conv_halo_s2_pw_cfg(conv_params(e, o));
-            if (c >= 0) { e.ops[o.fuse_pre].skip = true; o.cfg = 500 + c; o.kernel = conv_halo_s2_pw_kernel_name(c); continue; }
+            if (c >= 0) {
+                e.ops[o.fuse_pre].skip = true; o.cfg = 500 + c; o.kernel = conv_halo_s2_pw_kernel_name(c);
+                // ... and with the stem in front of it, when the stem's output has no other reader
+                static const bool no_front = [] { const char* v = std::getenv("YOLOP_NO_FRONT"); return v && *v == '1'; }();   // A/B switch
+                const Op& c1 = e.ops[o.fuse_pre];
+                int stem = -1, readers = 0;
+                for (size_t j = 0; j < e.ops.size(); ++j) {
+                    if (e.ops[j].kind == OP_STEM && e.ops[j].out.t == c1.in.t) stem = (int)j;
+                    for (const View* v : {&e.ops[j].in, &e.ops[j].res}) if (v->t == c1.in.t) ++readers;
+                }
+                if (stem >= 0 && readers == 1 && !no_front && e.weights[e.ops[stem].widx].d_w2 != nullptr) {
+                    o.stem_op = stem;
+                    if (frontend_valid(front_params(e, o, nullptr))) { o.fused3 = true; e.ops[stem].skip = true; o.kernel = "frontend_kernel"; }
+                }
+                continue;
+            }
             o.fused2 = false;
         }
         if (o.kind == OP_CONV && o.fuse_dw >= 0 && e.dtype == DT_BF16 && e.fuse) {
@@ -549,6 +565,20 @@ static ConvParams conv_params(const yp_engine& e, const Op& o) {
     return p;
 }
 
+static FrontParams front_params(const yp_engine& e, const Op& o, const uint8_t* img) {
+    const Op& c1 = e.ops[o.fuse_pre];
+    const Op& st = e.ops[o.stem_op];
+    const WeightDesc &w0 = e.weights[st.widx], &w1 = e.weights[c1.widx], &w2 = e.weights[o.widx];
+    const TensorDesc &t0 = e.tensors[st.out.t], &to = e.tensors[o.out.t];
+    FrontParams p{};
+    p.img = img; p.imgH = e.pH; p.imgW = e.pW; p.B = e.pB;
+    p.w0 = w0.d_w2; p.bias0 = w0.d_b; p.act0 = st.act; p.C0 = st.out.C; p.H1 = t0.H; p.W1 = t0.W;
+    p.w1 = w1.d_w; p.bias1 = w1.d_b; p.act1 = c1.act; p.C1 = c1.out.C; p.Kpad1 = w1.Kpad; p.w1_bytes = w1.mat_bytes;
+    p.w2 = w2.d_w; p.bias2 = w2.d_b; p.act2 = o.act; p.C2 = o.out.C; p.Kpad2 = w2.Kpad; p.w2_bytes = w2.mat_bytes;
+    p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.y_bytes = to.bytes; p.Ho = to.H; p.Wo = to.W;
+    return p;
+}
+
 static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_t st) {
     auto T = [&](const View& v) -> const TensorDesc& { return e.tensors[v.t]; };
     const int B = e.pB;
@@ -563,6 +593,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
         }
         case OP_CONV:
             if (o.fused) return launch_conv_dwpw(dwpw_params(e, o), st);
+            if (o.fused3) return launch_frontend(front_params(e, o, a.in), st);
             if (o.fused2) { const ConvParams q = conv_params(e, o); return launch_conv_halo_s2(q, o.cfg - 500, st); }
             return launch_conv(conv_params(e, o), e.dtype, st);
         case OP_CONVT: {
@@ -812,6 +843,7 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     rd.clear(); wr.clear();
     if (o.skip) return;
     if (o.fused) rd.push_back(e.ops[o.fuse_dw].in);
+    else if (o.fused3) { /* reads the caller's frames only */ }
     else if (o.fused2) rd.push_back(e.ops[o.fuse_pre].in);
     else if (o.in.t >= 0) rd.push_back(o.in);
     if (o.folded) rd.push_back(e.ops[o.fold_up].in);      // (besides the concat buffer, whose skip part it still reads)
