@@ -236,13 +236,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_dma_p_kernel(const ConvPa
             for (int a = 0; a < FN; ++a) {
                 const int co = n0 + wn * WN + a * 16 + fc * 4;
                 const bool ok = (m < p.M) && (co < p.Cout) && (p.dbg != 1);
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float tt = acc[a][b][i];
-                    if (p.act == ACT_SILU) tt = silu_f2(tt);
-                    v[i] = tt;
-                }
+                float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+                if (p.act == ACT_SILU) silu4_packed(v);
                 if (HAS_RES) {
                     const uint2 rr = rres[b][a];
                     v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);

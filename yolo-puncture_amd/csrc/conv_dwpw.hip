@@ -212,8 +212,10 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 __attribute__((aligned(8))) __bf16 o[4];
+                float sv[4] = {dacc[r][h][0], dacc[r][h][1], dacc[r][h][2], dacc[r][h][3]};
+                if (p.act_dw == ACT_SILU) silu4_packed(sv);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(p.act_dw == ACT_SILU ? silu_q(dacc[r][h][i]) : dacc[r][h][i]);
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)sv[i];
                 const int c8 = 2 * h + (fc >> 1);
                 *(uint2*)(asl + px * 64 + ((c8 ^ qswz(px)) * 16) + (fc & 1) * 8) = *(const uint2*)o;
             }
@@ -260,9 +262,8 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
             for (int a = 0; a < FN; ++a) {
                 const int co = n0 + wn * WN + a * 16 + fc * 4;
                 const bool ok = pix_ok && (co < p.Cout);
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (p.act_pw == ACT_SILU) ? silu_q(acc[a][bb][i]) : acc[a][bb][i];
+                float v[4] = {acc[a][bb][0], acc[a][bb][1], acc[a][bb][2], acc[a][bb][3]};
+                if (p.act_pw == ACT_SILU) silu4_packed(v);
                 if (OUT_F32) {
                     const unsigned off = ok ? (m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 4u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(v[0], v[1], v[2], v[3])), yrs, off, 0, 0);

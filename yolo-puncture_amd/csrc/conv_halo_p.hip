@@ -219,13 +219,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_p_kernel(const ConvP
                 for (int a = 0; a < FN; ++a) {
                     const int co = n0 + wn * (FN * 16) + a * 16 + fc * 4;
                     const bool ok = pix_ok && (co < p.Cout);
-                    float v[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float tt = acc[a][r][i];
-                        if (p.act == ACT_SILU) tt = silu_fast(tt);
-                        v[i] = tt;
-                    }
+                    float v[4] = {acc[a][r][0], acc[a][r][1], acc[a][r][2], acc[a][r][3]};
+                    if (p.act == ACT_SILU) silu4_packed(v);
                     if (HAS_RES) {
                         const uint2 rr = rres[r][a];
                         v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);

@@ -228,8 +228,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_s2_kernel(const Conv
                 for (int a = 0; a < FN; ++a) {
                     const int co = wn * (FN * 16) + a * 16 + fc * 4;
                     __attribute__((aligned(8))) __bf16 o[4];
+                    float sv[4] = {acc[a][r][0], acc[a][r][1], acc[a][r][2], acc[a][r][3]};
+                    if (p.act == ACT_SILU) silu4_packed(sv);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(p.act == ACT_SILU ? silu_s2(acc[a][r][i]) : acc[a][r][i]);
+                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)sv[i];
                     *(uint2*)(tb + px * 128 + (((co >> 3) ^ ((px >> 1) & 7)) * 16) + (co & 7) * 2) = *(const uint2*)o;
                 }
             }
@@ -291,13 +293,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_s2_kernel(const Conv
                 for (int a = 0; a < FN; ++a) {
                     const int co = n0 + wn * (FN * 16) + a * 16 + fc * 4;
                     const bool ok = pix_ok && (co < (PW2 ? p.C2 : p.Cout));
-                    float v[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float tt = acc[a][r][i];
-                        if ((PW2 ? p.act2 : p.act) == ACT_SILU) tt = silu_s2(tt);
-                        v[i] = tt;
-                    }
+                    float v[4] = {acc[a][r][0], acc[a][r][1], acc[a][r][2], acc[a][r][3]};
+                    if ((PW2 ? p.act2 : p.act) == ACT_SILU) silu4_packed(v);
                     if (HAS_RES) {
                         const uint2 rr = rres[r][a];
                         v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);

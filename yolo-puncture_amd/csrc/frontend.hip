@@ -21,6 +21,7 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ float silu_fe(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ void silu4(float* v) { silu4_packed(v); }
 __device__ __forceinline__ int fswz(int row) { return ((row >> 2) & 1) << 1; }
 
 constexpr int FE_TH = 8;                         // output rows per tile (4 waves in M x 2 rows)
@@ -199,8 +200,10 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
                 f32x4 acc = {bias0[h].x, bias0[h].y, bias0[h].z, bias0[h].w};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0f[h], xf, acc, 0, 0, 0);
                 __attribute__((aligned(8))) __bf16 o[4];
+                float sv[4] = {acc[0], acc[1], acc[2], acc[3]};
+                if (p.act0 == ACT_SILU) silu4(sv);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(in ? (p.act0 == ACT_SILU ? silu_fe(acc[i]) : acc[i]) : 0.f);
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(in ? sv[i] : 0.f);
                 if (hp < FE_HP) *(uint2*)(Hs + hp * 64 + (((2 * h + (fc >> 1)) ^ fswz(hp)) * 16) + (fc & 1) * 8) = *(const uint2*)o;
             }
         }
@@ -252,8 +255,10 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
             for (int a = 0; a < FN; ++a) {
                 const int co = wn * (FN * 16) + a * 16 + fc * 4;
                 __attribute__((aligned(8))) __bf16 o[4];
+                float sv[4] = {acc[a][r][0], acc[a][r][1], acc[a][r][2], acc[a][r][3]};
+                if (p.act1 == ACT_SILU) silu4(sv);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(p.act1 == ACT_SILU ? silu_fe(acc[a][r][i]) : acc[a][r][i]);
+                for (int i = 0; i < 4; ++i) o[i] = (__bf16)sv[i];
                 *(uint2*)(Hs + px * 128 + (((co >> 3) ^ ((px >> 1) & 7)) * 16) + (co & 7) * 2) = *(const uint2*)o;
             }
         }
@@ -291,9 +296,8 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
 #pragma unroll
             for (int a = 0; a < FN; ++a) {
                 const int co = wn * (FN * 16) + a * 16 + fc * 4;
-                float v[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[i] = (p.act2 == ACT_SILU) ? silu_fe(acc[a][r][i]) : acc[a][r][i];
+                float v[4] = {acc[a][r][0], acc[a][r][1], acc[a][r][2], acc[a][r][3]};
+                if (p.act2 == ACT_SILU) silu4(v);
                 const unsigned off = pix_ok ? (m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 2u : OOB;
                 __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
                 __builtin_amdgcn_raw_buffer_store_b64(*(const __attribute__((ext_vector_type(2))) unsigned*)o, yrs, off, 0, 0);

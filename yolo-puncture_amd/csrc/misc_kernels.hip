@@ -194,10 +194,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const StemParams p, cons
             const int mm = (int)blockIdx.x * 256 + wave * 64 + b * 16 + fr;
             if (mm >= M) continue;
             float v[4] = {acc[0] + bs.x, acc[1] + bs.y, acc[2] + bs.z, acc[3] + bs.w};
-            if (p.act == ACT_SILU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = silu_q(v[r]);
-            }
+            if (p.act == ACT_SILU) silu4_packed(v);
             __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
             *(uint2*)((__bf16*)p.y + (size_t)mm * p.y_stride + p.y_coff + co) = *(const uint2*)o;
         }

@@ -15,7 +15,7 @@ from .weights import fold_state
 
 _LIB: Optional[C.CDLL] = None
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolop.so")
+LIB_PATH = os.environ.get("YOLOP_LIB") or os.path.join(_HERE, "libyolop.so")     # YOLOP_LIB: another build of the same ABI (A/B runs)
 
 YP_BF16, YP_F32 = 0, 1
 TASK_DETECT, TASK_SEGMENT = 0, 1
