@@ -207,6 +207,10 @@ int conv_dma_p_num_cfgs();
 bool conv_dma_p_cfg_valid(const ConvParams& p, int c);
 const char* conv_dma_p_kernel_name(int c);
 hipError_t launch_conv_dma_p(const ConvParams& p, int c, hipStream_t st);
+int conv_tile1_num_cfgs();
+bool conv_tile1_cfg_valid(const ConvParams& p, int c);
+const char* conv_tile1_kernel_name(int c);
+hipError_t launch_conv_tile1(const ConvParams& p, int c, hipStream_t st);
 int conv_halo_s2_num_cfgs();
 bool conv_halo_s2_cfg_valid(const ConvParams& p, int c);
 const char* conv_halo_s2_kernel_name(int c);

@@ -1,0 +1,280 @@
+// One tile per compute unit: 3x3 stride-1 convolution for the mid-resolution layers (40x40 x 128 channels in v10-S), bf16.
+//
+// Those layers are 15 GFLOP over 51 200 pixels: every tiling of the implicit-GEMM families lands at 26-31 us (~500 TFLOP/s)
+// because a 128- or 256-pixel tile re-reads its pixels nine times through 1-KiB LDS-DMA pieces (~900 pieces per CU, and a
+// wave gets one piece through per ~240 cycles) and leaves 256 CUs with 200 or 400 tiles. Here the problem is cut into
+// EXACTLY one tile per CU - TR x TC output pixels with B*ceil(H/TR)*ceil(W/TC) <= 256 (10 x 20 at 40x40, batch 32) - and
+//   * the tile's input patch (TR+2) x (TC+2) x Cin is staged ONCE and stays in LDS (68 KB at Cin = 128),
+//   * the weights stream through a 3-slot ring exactly once per CU, one tap row (3 taps x [BN][32]) per stage and barrier,
+//     its pieces issued behind the MFMAs of the previous taps,
+//   * the pixels of a tile are taken 16 at a time in flattened row-major order: a lane of the MFMA B operand reads its own
+//     pixel's halo position, so a fragment may wrap around the tile's row end (no padding to a multiple of 16 columns).
+// 8 waves as WGM (pixel groups) x WGN (32 output channels each), WGM * WGN = 8; a wave holds up to FMX pixel fragments x 2
+// channel fragments.
+#include "common.h"
+
+namespace yp {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <int N> __device__ __forceinline__ void wait_vt1() {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    __builtin_amdgcn_s_waitcnt((N & 0xF) | (7 << 4) | (0xF << 8) | (((N >> 4) & 3) << 14));
+}
+__device__ __forceinline__ int tswz(int row) { return ((row >> 2) & 1) << 1; }
+
+constexpr int T1_FMX = 7;        // pixel fragments per wave (2 waves in M: tiles of up to 224 pixels)
+constexpr int T1_NS = 3;         // weight ring slots; a stage is one tap ROW (3 taps x [BN][32]) so that a barrier covers 6*FMX MFMAs per wave
+
+struct Tile1Geo { int TR, TC, tiles_h, tiles_w, nfr, ppc; };   // ppc: 16-pixel pieces per chunk plane of the patch
+
+template <int WGN, bool HAS_RES, bool OUT_F32>
+__global__ __launch_bounds__(512) void conv_tile1_kernel(const ConvParams p, const Tile1Geo g) {
+    constexpr int NW = 8, WGM = NW / WGN, FN = 2;
+    constexpr int BN = WGN * FN * 16;
+    constexpr int WP = BN * 64 / 1024;                 // weight pieces per k-step
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int nchunk = p.Cin >> 5;
+    unsigned char* const Xs = smem;                                        // [nchunk][ppc*16 px][32 ch]
+    unsigned char* const Ws = smem + (size_t)nchunk * g.ppc * 1024;       // [NS][BN][32 ch]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave % WGM, wn = wave / WGM;
+    const int fr = lane & 15, fc = lane >> 4;
+
+    const int ntn = (p.Cout + BN - 1) / BN;
+    int bid = blockIdx.x;
+    const int nt = bid % ntn;
+    int t = bid / ntn;
+    const int tw = t % g.tiles_w; t /= g.tiles_w;
+    const int th = t % g.tiles_h;
+    const int b = t / g.tiles_h;
+    const int r0 = th * g.TR, c0 = tw * g.TC, n0 = nt * BN;
+    const int HC = g.TC + 2;                                                // patch pitch in pixels
+
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
+
+    float bias[FN][4];
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        const int co = n0 + wn * (FN * 16) + a * 16 + fc * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[a][r] = (co + r < p.Cout) ? p.bias[co + r] : 0.f;
+    }
+
+    // ---- the input patch: chunk plane 0 now, plane c+1 at the start of chunk c's first stage (two stages before its first use;
+    // the counted waits of the weight ring are stricter than needed there, so they cover it) --------------------------------------
+    auto issue_x = [&](int ch) {
+        const int HR = g.TR + 2, npx = HR * HC;
+        for (int pi = wave; pi < g.ppc; pi += NW) {
+            const int hp = pi * 16 + (lane >> 2), pc = lane & 3;
+            const int c8 = pc ^ tswz(hp);
+            const int hy = hp / HC, hx = hp - hy * HC;
+            const int hi = r0 - 1 + hy, wi = c0 - 1 + hx;
+            const bool ok = hp < npx && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+            const unsigned voff = ok ? (unsigned)((((b * p.H + hi) * p.W + wi) * p.x_stride + p.x_coff + ch * 32 + c8 * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(Xs + (ch * g.ppc + pi) * 1024), 16, voff, 0, 0, 0);
+        }
+    };
+    issue_x(0);
+    // ---- weight ring: stage st = chunk * 3 + ky holds the three taps (ky, 0..2) as [3][BN][32] --------------------------------------
+    const int nst = nchunk * 3;
+    constexpr int SW = 3 * BN * 64;                                          // bytes per stage
+    constexpr int LPW = 3 * WP / 8 > 0 ? (3 * WP + 7) / 8 : 1;               // pieces per wave and stage (3 at BN = 128, 2 at BN = 64)
+    unsigned wbase[LPW];
+    bool wlive[LPW];
+#pragma unroll
+    for (int j = 0; j < LPW; ++j) {
+        const int q = wave + j * NW;                                         // piece id within the stage: kx = q / WP, rows (q % WP) * 16 ..
+        wlive[j] = q < 3 * WP;
+        const int kx = q / WP, n = (q % WP) * 16 + (lane >> 2), pc = lane & 3;
+        const int c8 = pc ^ tswz(n);
+        wbase[j] = (unsigned)(((n0 + n) * p.Kpad + kx * p.Cin + c8 * 8) * 2);
+    }
+    const bool full = wlive[LPW - 1];                                        // this wave carries LPW pieces per stage (else LPW - 1)
+    int it = 0;
+    auto issue_piece = [&](int j, int stage) {
+        const int ch = stage / 3, ky = stage - ch * 3;
+        if (!wlive[j]) return;                                               // (wave-uniform; an out-of-range piece would zero-fill LDS)
+        const unsigned voff = (stage < nst) ? wbase[j] + (unsigned)((ky * 3 * p.Cin + ch * 32) * 2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(Ws + (stage % T1_NS) * SW + (wave + j * NW) * 1024), 16, voff, 0, 0, 0);
+    };
+#pragma unroll
+    for (int s2 = 0; s2 < T1_NS - 1; ++s2) {
+#pragma unroll
+        for (int j = 0; j < LPW; ++j) issue_piece(j, it);
+        ++it;
+    }
+
+    // ---- this wave's pixel fragments: flattened pixel -> patch position of tap (0,0) ------------------------------------------------
+    const int npix = g.TR * g.TC;
+    const int per_wave = (g.nfr + WGM - 1) / WGM;
+    const int f0 = wm * per_wave;                                            // first fragment of this wave
+    int hbase[T1_FMX];
+#pragma unroll
+    for (int f = 0; f < T1_FMX; ++f) {
+        int pp = (f0 + f) * 16 + fr;
+        if (pp >= npix) pp = npix - 1;                                       // padding lanes read a valid pixel, never stored
+        const int r = pp / g.TC, c = pp - r * g.TC;
+        hbase[f] = r * HC + c;
+    }
+    const int myf = max(0, min(per_wave, g.nfr - f0));                       // fragments that exist for this wave (wave-uniform)
+
+    f32x4 acc[FN][T1_FMX];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int f = 0; f < T1_FMX; ++f) acc[a][f] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};
+
+    if (full) wait_vt1<(T1_NS - 1) * LPW>();         // the patch has landed (only the ring's weight pieces may still be in flight)
+    else wait_vt1<(T1_NS - 1) * (LPW - 1)>();
+    __builtin_amdgcn_s_barrier();
+
+    for (int st = 0; st < nst; ++st) {
+        if (full) wait_vt1<(T1_NS - 2) * LPW>();     // this wave's pieces of stage st have landed
+        else wait_vt1<(T1_NS - 2) * (LPW - 1)>();
+        __builtin_amdgcn_s_barrier();
+        const int ch = st / 3, ky = st - ch * 3;
+        if (ky == 0 && ch + 1 < nchunk) issue_x(ch + 1);
+        const unsigned char* ws = Ws + (st % T1_NS) * SW;
+        const unsigned char* xs = Xs + (size_t)ch * g.ppc * 1024;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tapoff = ky * HC + kx;
+            bf16x8 wf[FN], xf[T1_FMX];
+#pragma unroll
+            for (int a = 0; a < FN; ++a) {
+                const int rw = kx * BN + wn * (FN * 16) + a * 16 + fr;
+                wf[a] = *(const bf16x8*)(ws + rw * 64 + ((fc ^ tswz(rw)) * 16));
+            }
+            // straight-line: every fragment read is issued before the first MFMA waits for one. Fragments beyond the wave's share
+            // recompute a valid pixel and are never stored.
+#pragma unroll
+            for (int f = 0; f < T1_FMX; ++f) {
+                const int hp = hbase[f] + tapoff;
+                xf[f] = *(const bf16x8*)(xs + hp * 64 + ((fc ^ tswz(hp)) * 16));
+            }
+#pragma unroll
+            for (int f = 0; f < T1_FMX; ++f)
+#pragma unroll
+                for (int a = 0; a < FN; ++a) acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[f], acc[a][f], 0, 0, 0);
+            // one piece of stage st + NS - 1 behind each tap's MFMAs: the ~300-cycle issue stall runs under their execution; the
+            // slot it overwrites (stage st - 1) was finished with before this stage's barrier
+            if (kx < LPW) issue_piece(kx, it);
+        }
+        ++it;
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int f = 0; f < T1_FMX; ++f) {
+        if (f >= myf) continue;
+        const int pp = (f0 + f) * 16 + fr;
+        const int r = pp / g.TC, c = pp - r * g.TC;
+        const int ho = r0 + r, wo = c0 + c;
+        const bool pix_ok = pp < npix && ho < p.Ho && wo < p.Wo;
+        const unsigned m = (unsigned)((b * p.Ho + ho) * p.Wo + wo);
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int co = n0 + wn * (FN * 16) + a * 16 + fc * 4;
+            const bool ok = pix_ok && co < p.Cout;
+            float v[4] = {acc[a][f][0], acc[a][f][1], acc[a][f][2], acc[a][f][3]};
+            if (p.act == ACT_SILU) silu4_packed(v);
+            if (HAS_RES) {
+                const uint2 rr = ok ? *(const uint2*)((const __bf16*)p.res + (size_t)m * p.res_stride + p.res_coff + co) : make_uint2(0u, 0u);
+                v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            }
+            if (OUT_F32) {
+                const unsigned off = ok ? (m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 4u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(v[0], v[1], v[2], v[3])), yrs, off, 0, 0);
+            } else {
+                const unsigned off = ok ? (m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 2u : OOB;
+                __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                __builtin_amdgcn_raw_buffer_store_b64(*(const __attribute__((ext_vector_type(2))) unsigned*)o, yrs, off, 0, 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// host: pick TR x TC so that the whole problem is one round of at most 256 workgroups
+static bool tile1_geometry(const ConvParams& p, int BN, Tile1Geo& g, size_t& lds) {
+    const int WGM = 8 / (BN / 32);
+    const int B = p.M / (p.Ho * p.Wo);
+    const int ntn = (p.Cout + BN - 1) / BN;
+    const int nchunk = p.Cin / 32;
+    double best = 0;
+    bool found = false;
+    for (int TR = 1; TR <= p.Ho; ++TR)
+        for (int TC = 4; TC <= p.Wo; ++TC) {
+            const int px = TR * TC;
+            if (px > WGM * T1_FMX * 16) break;
+            const int tiles = B * ((p.Ho + TR - 1) / TR) * ((p.Wo + TC - 1) / TC) * ntn;
+            if (tiles > 256) continue;
+            const int ppc = ((TR + 2) * (TC + 2) + 15) / 16;
+            const size_t sh = (size_t)nchunk * ppc * 1024 + (size_t)T1_NS * 3 * BN * 64;
+            if (sh > 160 * 1024) continue;
+            const int nfr = (px + 15) / 16;
+            const int per_wave = (nfr + WGM - 1) / WGM;                    // fragments of the busiest pixel group
+            // time ~ per_wave MFMA pairs per k-step; prefer fewer, then more CUs used
+            const double score = 1000.0 / per_wave + tiles / 256.0 + (double)B * p.Ho * p.Wo * ntn / ((double)tiles * nfr * 16) * 0.1;
+            if (score > best) { best = score; g = Tile1Geo{TR, TC, (p.Ho + TR - 1) / TR, (p.Wo + TC - 1) / TC, nfr, ppc}; lds = sh; found = true; }
+        }
+    return found;
+}
+
+int conv_tile1_num_cfgs() { return 2; }
+const char* conv_tile1_kernel_name(int c) { return c == 0 ? "conv_tile1_kernel<4>" : "conv_tile1_kernel<2>"; }
+
+bool conv_tile1_cfg_valid(const ConvParams& p, int c) {
+    if (c < 0 || c >= 2) return false;
+    if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.up != 1 || (p.Cin % 32) != 0 || p.Kpad != 9 * p.Cin || p.x2_C > 0) return false;
+    if (p.x_bytes >= (1ull << 31) || p.w_bytes >= (1ull << 31) || p.y_bytes >= (1ull << 31)) return false;
+    if ((p.Cout & 3) || (p.y_stride & 3) || (p.y_coff & 3) || (p.res && ((p.res_stride & 3) || (p.res_coff & 3)))) return false;
+    if (p.res && p.out_f32) return false;
+    const int BN = c == 0 ? 128 : 64;
+    if (BN > (p.Cout + 31) / 32 * 32) return false;
+    Tile1Geo g;
+    size_t lds;
+    if (!tile1_geometry(p, BN, g, lds)) return false;
+    return true;                                   // (whether one round of tiles pays is the autotuner's call)
+}
+
+template <int WGN, bool HAS_RES, bool OUT_F32>
+static hipError_t launch_tile1_var(const ConvParams& p, hipStream_t st) {
+    constexpr int BN = WGN * 32;
+    Tile1Geo g;
+    size_t sh;
+    if (!tile1_geometry(p, BN, g, sh)) return hipErrorInvalidValue;
+    const int B = p.M / (p.Ho * p.Wo);
+    const int tiles = B * g.tiles_h * g.tiles_w * ((p.Cout + BN - 1) / BN);
+    auto kern = conv_tile1_kernel<WGN, HAS_RES, OUT_F32>;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), sh, st, p, g);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_tile1(const ConvParams& p, int c, hipStream_t st) {
+    if (c == 0) {
+        if (p.out_f32) return launch_tile1_var<4, false, true>(p, st);
+        if (p.res) return launch_tile1_var<4, true, false>(p, st);
+        return launch_tile1_var<4, false, false>(p, st);
+    }
+    if (p.out_f32) return launch_tile1_var<2, false, true>(p, st);
+    if (p.res) return launch_tile1_var<2, true, false>(p, st);
+    return launch_tile1_var<2, false, false>(p, st);
+}
+
+}  // namespace yp

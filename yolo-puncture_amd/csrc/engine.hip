@@ -524,7 +524,7 @@ static int allocate_plan(yp_engine& e) {
             e.head_ws_bytes = need;
         }
     }
-    if (e.gexec) { (void)hipGraphExecDestroy(e.gexec); e.gexec = nullptr; }
+    if (e.gexec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(e.gexec); e.gexec = nullptr; }   // (never under a running replay)
     e.allocated = true;
     return YP_OK;
 }
@@ -740,6 +740,8 @@ static int autotune(yp_engine& e) {
             for (int c = 0; c < conv_dma_p_num_cfgs(); ++c) if (conv_dma_p_cfg_valid(p, c)) cands.push_back(300 + c);
             static const bool no_s2 = [] { const char* v = std::getenv("YOLOP_NO_S2"); return v && *v == '1'; }();   // A/B switch
             for (int c = 0; !no_s2 && c < conv_halo_s2_num_cfgs(); ++c) if (conv_halo_s2_cfg_valid(p, c)) cands.push_back(500 + c);
+            static const bool no_t1 = [] { const char* v = std::getenv("YOLOP_NO_T1"); return v && *v == '1'; }();   // A/B switch
+            for (int c = 0; !no_t1 && c < conv_tile1_num_cfgs(); ++c) if (conv_tile1_cfg_valid(p, c)) cands.push_back(600 + c);
             static const bool no_lc = [] { const char* v = std::getenv("YOLOP_NO_LC"); return v && *v == '1'; }();   // A/B switch
             for (int c = 0; !no_lc && c < conv_dma_lc_num_cfgs(); ++c) if (conv_dma_lc_cfg_valid(p, c)) cands.push_back(400 + c);
             for (int cc : cands) {
@@ -815,7 +817,7 @@ static DwPwParams dwpw_params(const yp_engine& e, const Op& c) {
 // the persistent conv kernels are additionally templated on <HAS_RES, OUT_F32>: make the reported symbol exact
 static void finish_kernel_names(yp_engine& e) {
     for (Op& o : e.ops) {
-        const bool lc = o.kernel.find("_lc_kernel<") != std::string::npos || o.kernel.find("_s2_kernel<") != std::string::npos;
+        const bool lc = o.kernel.find("_lc_kernel<") != std::string::npos || o.kernel.find("_s2_kernel<") != std::string::npos || o.kernel.find("_tile1_kernel<") != std::string::npos;
         if ((o.kernel.find("_p_kernel<") == std::string::npos && !lc) || o.kernel.find(",false>") != std::string::npos || o.kernel.find(",true>") != std::string::npos) continue;
         const bool f32 = (o.kind == OP_CONV) && e.tensors[o.out.t].f32 && e.dtype == DT_BF16;
         const bool res = o.res.t >= 0;
@@ -1025,11 +1027,26 @@ extern "C" {
 
 const char* yp_last_error(void) { return g_err; }
 
+// Debug aid (env YOLOP_SEGV_TRACE=1): print a native backtrace when the process takes a SIGSEGV inside the library
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+static void yp_segv_handler(int sig) {
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    const char msg[] = "\n[yolop] SIGSEGV - native backtrace:\n";
+    (void)!write(2, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+
 int yp_create(const yp_model_desc* desc, int device, yp_engine** out) {
     if (!desc || !out) return fail(YP_ERR_ARG, "null argument");
     if (desc->nc <= 0 || desc->max_det <= 0 || desc->max_det > 1024) return fail(YP_ERR_ARG, "bad nc/max_det");
     if (desc->dtype != YP_BF16 && desc->dtype != YP_F32) return fail(YP_ERR_ARG, "bad dtype");
     if (desc->task != YP_TASK_DETECT && desc->task != YP_TASK_SEGMENT) return fail(YP_ERR_ARG, "bad task");
+    { const char* tr = std::getenv("YOLOP_SEGV_TRACE"); if (tr && *tr == '1') signal(SIGSEGV, yp_segv_handler); }
     std::unique_ptr<yp_engine> e(new yp_engine());
     e->desc = *desc; e->device = device; e->dtype = desc->dtype;
     { const char* nf = std::getenv("YOLOP_NO_FUSE"); e->fuse = !(nf && *nf == '1'); }
@@ -1045,7 +1062,7 @@ int yp_create(const yp_model_desc* desc, int device, yp_engine** out) {
 
 int yp_destroy(yp_engine* e) {
     if (!e) return YP_OK;
-    if (e->finalized || e->arena) (void)hipSetDevice(e->device);
+    if (e->finalized || e->arena) { (void)hipSetDevice(e->device); (void)hipDeviceSynchronize(); }   // nothing of this engine may still be running
     for (auto& w : e->weights) { if (w.d_w) (void)hipFree(w.d_w); if (w.d_w2) (void)hipFree(w.d_w2); if (w.d_b) (void)hipFree(w.d_b); }
     if (e->arena) (void)hipFree(e->arena);
     if (e->mask_ws) (void)hipFree(e->mask_ws);
@@ -1239,7 +1256,13 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     // hipGraph replay on the engine's own stream, ordered against the caller's stream by events
     yp_engine::Key k{B, H, W, in_dev, det_out, idx_out, coeff_out};
     if (!e->gexec || memcmp(&k, &e->gkey, sizeof(k)) != 0) {
-        if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        if (e->gexec) {
+            // the previous executable may still be running (replays are asynchronous): destroying it under the GPU is a
+            // use-after-free inside the runtime (seen as a rare SIGSEGV when every call brought new output buffers)
+            HIPCHK(hipStreamSynchronize(e->own_stream));
+            (void)hipGraphExecDestroy(e->gexec);
+            e->gexec = nullptr;
+        }
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
         rc = e->use_lanes ? run_all_lanes(*e, a) : run_all(*e, a, e->own_stream);
@@ -1296,7 +1319,7 @@ int yp_set_graph(yp_engine* e, int enable) {
     if (!e) return fail(YP_ERR_ARG, "null engine");
     e->use_graph = enable != 0;
     e->use_lanes = enable != 2;          // 2 = graph without concurrent lanes (A/B measurements)
-    if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+    if (e->gexec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
     return YP_OK;
 }
 

@@ -256,7 +256,12 @@ class YOLO:
             for bi, i in enumerate(idxs):
                 raw = torch.from_numpy(np.ascontiguousarray(imgs[i])).to(dev, non_blocking=True)
                 letterbox_device(raw, geos[i], out=batch[bi])
-            out = eng.forward(batch)
+            # one output set per batch size: new buffers on every call would re-capture the engine's hipGraph each time (it is
+            # keyed on its output pointers); everything handed to the caller below is copied out of these buffers
+            cache = self.__dict__.setdefault("_out_cache", {})
+            okey = (self._dev_index, len(idxs))
+            out = eng.forward(batch, cache.get(okey))
+            cache[okey] = out
             det = out["det"]
             for bi, i in enumerate(idxs):
                 oh, ow = imgs[i].shape[:2]
