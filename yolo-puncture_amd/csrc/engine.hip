@@ -62,7 +62,11 @@ struct yp_engine {
     std::vector<hipStream_t> lane_streams;   // [0] unused (lane 0 = own_stream)
     std::vector<hipEvent_t> lane_events;
     bool use_lanes = true;
-    struct Key { int B, H, W; const void* in; void* det; void* idx; void* coeff; } gkey{};
+    struct Key { int B = 0, H = 0, W = 0; const void* in = nullptr; } gkey;   // what the captured graph is specialised on
+    // engine-owned results of the replayed graph: the graph never references the caller's output buffers (they change from
+    // call to call in ordinary use, and every change would mean capture + instantiate + destroy); yp_forward copies the
+    // ~0.3 MB out behind the replay
+    float* o_det = nullptr; int32_t* o_idx = nullptr; float* o_coeff = nullptr; size_t o_cap = 0;
     int es() const { return dtype == DT_BF16 ? 2 : 4; }
 };
 
@@ -523,6 +527,14 @@ static int allocate_plan(yp_engine& e) {
             HIPCHK(hipMalloc(&e.head_ws, need));
             e.head_ws_bytes = need;
         }
+    }
+    if ((size_t)e.pB > e.o_cap) {
+        if (e.o_det) { HIPCHK(hipFree(e.o_det)); HIPCHK(hipFree(e.o_idx)); HIPCHK(hipFree(e.o_coeff)); }
+        const size_t rows = (size_t)e.pB * e.desc.max_det;
+        HIPCHK(hipMalloc(&e.o_det, rows * 6 * sizeof(float)));
+        HIPCHK(hipMalloc(&e.o_idx, rows * sizeof(int32_t)));
+        HIPCHK(hipMalloc(&e.o_coeff, rows * 32 * sizeof(float)));
+        e.o_cap = (size_t)e.pB;
     }
     if (e.gexec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(e.gexec); e.gexec = nullptr; }   // (never under a running replay)
     e.allocated = true;
@@ -1067,6 +1079,7 @@ int yp_destroy(yp_engine* e) {
     if (e->arena) (void)hipFree(e->arena);
     if (e->mask_ws) (void)hipFree(e->mask_ws);
     if (e->head_ws) (void)hipFree(e->head_ws);
+    if (e->o_det) { (void)hipFree(e->o_det); (void)hipFree(e->o_idx); (void)hipFree(e->o_coeff); }
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
@@ -1253,29 +1266,36 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     RunArgs a{in_dev, det_out, idx_out, coeff_out};
     if (!e->use_graph) return run_all(*e, a, st);
 
-    // hipGraph replay on the engine's own stream, ordered against the caller's stream by events
-    yp_engine::Key k{B, H, W, in_dev, det_out, idx_out, coeff_out};
-    if (!e->gexec || memcmp(&k, &e->gkey, sizeof(k)) != 0) {
+    // hipGraph replay on the engine's own stream, ordered against the caller's stream by events. The graph is specialised on
+    // the plan and on the INPUT pointer only (frames are read in place); results land in engine-owned buffers.
+    const bool seg = e->desc.task == YP_TASK_SEGMENT;
+    RunArgs ag{in_dev, e->o_det, e->o_idx, seg ? e->o_coeff : nullptr};
+    if (!e->gexec || e->gkey.B != B || e->gkey.H != H || e->gkey.W != W || e->gkey.in != (const void*)in_dev) {
         if (e->gexec) {
-            // the previous executable may still be running (replays are asynchronous): destroying it under the GPU is a
-            // use-after-free inside the runtime (seen as a rare SIGSEGV when every call brought new output buffers)
+            // the previous executable may still be running (replays are asynchronous): never destroy it under the GPU
             HIPCHK(hipStreamSynchronize(e->own_stream));
             (void)hipGraphExecDestroy(e->gexec);
             e->gexec = nullptr;
         }
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
-        rc = e->use_lanes ? run_all_lanes(*e, a) : run_all(*e, a, e->own_stream);
+        rc = e->use_lanes ? run_all_lanes(*e, ag) : run_all(*e, ag, e->own_stream);
         hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
         if (rc != YP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (ce != hipSuccess) return fail(YP_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
         HIPCHK(hipGraphInstantiate(&e->gexec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
-        e->gkey = k;
+        e->gkey.B = B; e->gkey.H = H; e->gkey.W = W; e->gkey.in = in_dev;
     }
     HIPCHK(hipEventRecord(e->ev_in, st));
     HIPCHK(hipStreamWaitEvent(e->own_stream, e->ev_in, 0));
     HIPCHK(hipGraphLaunch(e->gexec, e->own_stream));
+    {
+        const size_t rows = (size_t)B * e->desc.max_det;
+        HIPCHK(hipMemcpyAsync(det_out, e->o_det, rows * 6 * sizeof(float), hipMemcpyDeviceToDevice, e->own_stream));
+        if (idx_out) HIPCHK(hipMemcpyAsync(idx_out, e->o_idx, rows * sizeof(int32_t), hipMemcpyDeviceToDevice, e->own_stream));
+        if (coeff_out && seg) HIPCHK(hipMemcpyAsync(coeff_out, e->o_coeff, rows * 32 * sizeof(float), hipMemcpyDeviceToDevice, e->own_stream));
+    }
     HIPCHK(hipEventRecord(e->ev_out, e->own_stream));
     HIPCHK(hipStreamWaitEvent(st, e->ev_out, 0));
     return YP_OK;

@@ -252,7 +252,12 @@ class YOLO:
         out_by_index: Dict[int, Results] = {}
         for (H, W), idxs in groups.items():
             # the raw frame goes up once; resize + pad-114 run on the device straight into the batch tensor (yp_letterbox)
-            batch = torch.empty((len(idxs), H, W, 3), dtype=torch.uint8, device=dev)
+            # (one persistent batch buffer per shape: the engine's hipGraph is specialised on the input pointer)
+            bcache = self.__dict__.setdefault("_batch_cache", {})
+            bkey = (self._dev_index, len(idxs), H, W)
+            batch = bcache.get(bkey)
+            if batch is None:
+                batch = bcache[bkey] = torch.empty((len(idxs), H, W, 3), dtype=torch.uint8, device=dev)
             for bi, i in enumerate(idxs):
                 raw = torch.from_numpy(np.ascontiguousarray(imgs[i])).to(dev, non_blocking=True)
                 letterbox_device(raw, geos[i], out=batch[bi])
@@ -300,7 +305,10 @@ class YOLO:
         dev = torch.device("cuda", self._dev_index)
         geo = hostops.letterbox_geometry(oh, ow, imgsz)
         H, W = geo["out_h"], geo["out_w"]
-        batch = torch.empty((1, H, W, 3), dtype=torch.uint8, device=dev)
+        bcache = self.__dict__.setdefault("_batch_cache", {})
+        batch = bcache.get((self._dev_index, 1, H, W))
+        if batch is None:
+            batch = bcache[(self._dev_index, 1, H, W)] = torch.empty((1, H, W, 3), dtype=torch.uint8, device=dev)
         letterbox_device(torch.from_numpy(np.ascontiguousarray(im)).to(dev), geo, out=batch[0])
         out = eng.forward(batch)
         d = out["det"][0]
