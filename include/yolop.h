@@ -15,6 +15,7 @@
 #ifndef YOLOP_H
 #define YOLOP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -99,6 +100,18 @@ int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev
  *    The geometry is the caller's (LetterBox arithmetic is host integer math: predictor.py / hostops.letterbox_geometry). */
 int yp_letterbox(const uint8_t* src_dev, int h0, int w0, uint8_t* dst_dev, int out_h, int out_w, int new_h, int new_w,
                  int top, int left, int pad_value, void* stream);
+
+/* -- multi-GPU: frames are sharded over one process per GPU; the only data-path collective is ONE all-gather of
+ *    the [B/G,max_det,6] detections per batch over RCCL (xGMI). The reference has no multi-GPU path (frames are independent inside
+ *    `.predict`, yolo_seg/app.py:85-91). bench.py / parallel.py use torch.distributed's "nccl" backend for it; these entry points
+ *    give a host without PyTorch the same collective. librccl.so is resolved at run time (dlopen).
+ *      rank 0: yp_comm_unique_id(id) -> ship the 128 bytes to every rank (any channel) -> all ranks: yp_comm_create(id, rank, world, dev)
+ *      yp_allgather: recv_dev holds world * bytes_per_rank bytes in rank order; enqueued on `stream`. */
+typedef struct yp_comm yp_comm;
+int yp_comm_unique_id(void* id128);
+int yp_comm_create(const void* id128, int rank, int world, int device, yp_comm** out);
+int yp_allgather(yp_comm* c, const void* send_dev, void* recv_dev, size_t bytes_per_rank, void* stream);
+int yp_comm_destroy(yp_comm* c);
 
 /* -- introspection (tests, bench): the planned op list for an input shape; host only. */
 int yp_plan(yp_engine* e, int B, int H, int W);            /* (re)build the plan; returns #ops or <0 */

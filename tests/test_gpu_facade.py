@@ -153,3 +153,23 @@ def test_device_letterbox_rejects_bad_arguments():
         letterbox_device(img, dict(out_h=8, out_w=8, new_h=8, new_w=8, top=0, left=0))          # host tensor
     with pytest.raises(YolopError):
         letterbox_device(img.cuda(), dict(out_h=8, out_w=8, new_h=9, new_w=8, top=0, left=0))   # does not fit
+
+
+def test_cabi_allgather_single_rank():
+    """yp_comm_* / yp_allgather (RCCL through the C-ABI, no torch.distributed): with one rank the gather is the identity;
+    the 2..8-rank form is the same call (the driver's scaling runs use the torch.distributed twin in bench.py)."""
+    import ctypes as C
+    from yolo_puncture_amd.engine import load_library
+    lib = load_library()
+    uid = (C.c_char * 128)()
+    assert lib.yp_comm_unique_id(uid) == 0, lib.yp_last_error().decode()
+    comm = C.c_void_p()
+    assert lib.yp_comm_create(uid, 0, 1, 0, C.byref(comm)) == 0, lib.yp_last_error().decode()
+    send = torch.rand(32, 300, 6, device="cuda")
+    recv = torch.zeros_like(send)
+    st = torch.cuda.current_stream().cuda_stream
+    assert lib.yp_allgather(comm, C.c_void_p(send.data_ptr()), C.c_void_p(recv.data_ptr()), send.numel() * 4, C.c_void_p(st)) == 0, \
+        lib.yp_last_error().decode()
+    torch.cuda.synchronize()
+    assert torch.equal(send, recv)
+    assert lib.yp_comm_destroy(comm) == 0

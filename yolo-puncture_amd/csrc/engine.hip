@@ -27,6 +27,7 @@ static int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+extern "C" int yp_fail_public(int code, const char* msg) { return fail(code, "%s", msg); }   // for the other translation units
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
         hipError_t _e = (x);                                                                        \
