@@ -7,6 +7,7 @@
 // Order of arithmetic follows the reference: fp32 GEMM at prototype resolution first, then 4-tap interpolation
 // (PyTorch upsample_bilinear2d, align_corners=False: src = scale*(dst+0.5)-0.5 clamped at 0).
 #include "common.h"
+#include <cstdlib>
 
 namespace yp {
 
@@ -48,6 +49,42 @@ __global__ __launch_bounds__(256) void mask_gemm_kernel(const MaskParams p, floa
 #pragma unroll
         for (int k = 0; k < 32; ++k) acc = fmaf(c[k], pv[k], acc);
         M[(size_t)i * p.ch * p.cw + pix] = acc;
+    }
+}
+
+// The same product on the matrix cores (the "batched MFMA GEMM" of the prototype tail): D[mask][pixel] = coeff[mask][k] *
+// proto[pixel][k] with v_mfma_f32_16x16x4_f32 - exact fp32 FMAs accumulated in k order, i.e. the very chain
+// fmaf(c[k], p[k], acc) of the scalar kernel above, so the two give the same bits (tests compare the tail with the oracle
+// either way). One wave = 16 pixels x all masks, 16 masks per accumulator; coefficients are read from LDS as the A operand.
+typedef __attribute__((ext_vector_type(4))) float mf32x4;
+template <typename T>
+__global__ __launch_bounds__(256) void mask_gemm_mfma_kernel(const MaskParams p, float* M) {
+    extern __shared__ float cs[];   // [ceil16(n)][32], rows >= n zero
+    const int npad = (p.n + 15) & ~15;
+    for (int i = threadIdx.x; i < npad * 32; i += blockDim.x) cs[i] = (i < p.n * 32) ? p.coeff[i] : 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int fr = lane & 15, fk = lane >> 4;
+    const int npix = p.ch * p.cw;
+    const int pix0 = (blockIdx.x * 4 + wave) * 16;
+    if (pix0 >= npix) return;
+    const int pix = min(pix0 + fr, npix - 1);                     // padding lanes recompute the last pixel, never stored
+    const int y = pix / p.cw, x = pix - y * p.cw;
+    const T* pp = (const T*)p.proto + ((size_t)(p.t + y) * p.Wp + (p.l + x)) * 32;
+    float b[8];                                                   // B operand: proto[pixel fr][k = 4j + fk]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) b[j] = (float)pp[4 * j + fk];
+    for (int m0 = 0; m0 < npad; m0 += 16) {
+        mf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(cs[(m0 + fr) * 32 + 4 * j + fk], b[j], acc, 0, 0, 0);
+        if (pix0 + fr < npix) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + fk * 4 + i;                    // D rows: mask index
+                if (m < p.n) M[(size_t)m * npix + pix0 + fr] = acc[i];
+            }
+        }
     }
 }
 
@@ -114,7 +151,7 @@ hipError_t launch_masks(const MaskParams& p, int dtype, hipStream_t st) {
         if (p.ids) return hipMemsetAsync(p.ids, 0, (size_t)p.oh * p.ow * sizeof(int64_t), st);
         return hipSuccess;
     }
-    if ((size_t)p.n * 32 * sizeof(float) > 60 * 1024) return hipErrorInvalidValue;
+    if ((size_t)((p.n + 15) & ~15) * 32 * sizeof(float) > 60 * 1024) return hipErrorInvalidValue;
     int32_t* area = p.area;
     int32_t* kept_ws = area + p.n;
     float* M = (float*)(area + 2 * (size_t)((p.n + 3) & ~3));
@@ -122,9 +159,16 @@ hipError_t launch_masks(const MaskParams& p, int dtype, hipStream_t st) {
     hipError_t e = hipMemsetAsync(area, 0, (size_t)p.n * sizeof(int32_t), st);
     if (e != hipSuccess) return e;
     const int npix = p.ch * p.cw;
-    const size_t sh = (size_t)p.n * 32 * sizeof(float);
-    if (dtype == DT_BF16) hipLaunchKernelGGL(mask_gemm_kernel<__bf16>, dim3((npix + 255) / 256), dim3(256), sh, st, p, M);
-    else hipLaunchKernelGGL(mask_gemm_kernel<float>, dim3((npix + 255) / 256), dim3(256), sh, st, p, M);
+    static const bool valu_gemm = [] { const char* v = std::getenv("YOLOP_MASK_VALU"); return v && *v == '1'; }();   // A/B: scalar form
+    if (valu_gemm) {
+        const size_t sh = (size_t)p.n * 32 * sizeof(float);
+        if (dtype == DT_BF16) hipLaunchKernelGGL(mask_gemm_kernel<__bf16>, dim3((npix + 255) / 256), dim3(256), sh, st, p, M);
+        else hipLaunchKernelGGL(mask_gemm_kernel<float>, dim3((npix + 255) / 256), dim3(256), sh, st, p, M);
+    } else {
+        const size_t sh = (size_t)((p.n + 15) & ~15) * 32 * sizeof(float);
+        if (dtype == DT_BF16) hipLaunchKernelGGL(mask_gemm_mfma_kernel<__bf16>, dim3((npix + 63) / 64), dim3(256), sh, st, p, M);
+        else hipLaunchKernelGGL(mask_gemm_mfma_kernel<float>, dim3((npix + 63) / 64), dim3(256), sh, st, p, M);
+    }
     hipLaunchKernelGGL(mask_resize_kernel, dim3((p.oh * p.ow + 255) / 256, p.n), dim3(256), 0, st, p, M, masks, area);
     if (p.ids) {
         int32_t* kept = p.kept ? p.kept : kept_ws;
