@@ -79,6 +79,8 @@ struct Op {
     bool fused3 = false;          // plan decision: stem -> 3x3 s2 -> this 1x1 run as frontend_kernel
     int fold_up = -1;             // OP_CONV 1x1 on a [upsampled | skip] concat: index of the nearest-x2 upsample op it can absorb
     bool folded = false;          // plan decision: the upsample is folded into this conv's input gather
+    int c2f_m1 = -1, c2f_m2 = -1; // OP_CONV 1x1 closing a C2f with one plain bottleneck: indices of the bottleneck's two 3x3 convs
+    bool fused4 = false;          // plan decision: both 3x3 convs and this 1x1 run as c2f_fused_kernel
     int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
 };
 
@@ -137,6 +139,20 @@ struct FrontParams {
 };
 bool frontend_valid(const FrontParams& p);
 hipError_t launch_frontend(const FrontParams& p, hipStream_t st);
+
+// fused C2f tail (c2f_fused.hip): [a | b] -> 3x3 -> 3x3 (+ b) -> 1x1 over [a | b | c]
+struct C2fParams {
+    const void* x; int x_stride, x_coff; size_t x_bytes;                 // the concat buffer: a = channels [coff, coff+C), b = the next C
+    int B, H, W, C;
+    const void* w1; const float* bias1; int act1, Kpad1; size_t w1_bytes;   // m.0.cv1: packed [C^][9*C]
+    const void* w2; const float* bias2; int act2, Kpad2; size_t w2_bytes;   // m.0.cv2: packed [C^][9*C]
+    int shortcut;                                                         // c += b
+    const void* w3; const float* bias3; int act3, Kpad3, Cout; size_t w3_bytes;   // cv2: packed [Cout^][3*C]
+    void* y; int y_stride, y_coff; size_t y_bytes;
+    unsigned long long* clk;                                              // debug (YOLOP_C2F_CLOCKS=1): per-wave stage clocks, else null
+};
+bool c2f_fused_valid(const C2fParams& p);
+hipError_t launch_c2f_fused(const C2fParams& p, hipStream_t st);
 
 struct PoolParams {
     const void* x; int x_stride, x_coff;

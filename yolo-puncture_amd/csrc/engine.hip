@@ -137,6 +137,7 @@ struct Builder {
     void c2f(const std::string& p, View in, View out, int c2, int n, bool shortcut, bool cib, bool lk) {
         const int c = c2 / 2, sd = sdiv_of(in);
         const int Y = tensor(p + ".cat", (2 + n) * c, sd);
+        int m1 = -1;
         conv(p + ".cv1", in, View{Y, 0, 2 * c}, 1, 1, ACT_SILU);
         for (int j = 0; j < n; ++j) {
             const View x{Y, (1 + j) * c, c}, y{Y, (2 + j) * c, c};
@@ -146,6 +147,7 @@ struct Builder {
                 const int t = tensor(q + ".cv1", c, sd);
                 conv(q + ".cv1", x, full(t), 3, 1, ACT_SILU);
                 conv(q + ".cv2", full(t), y, 3, 1, ACT_SILU, res);
+                if (n == 1) m1 = (int)e.ops.size() - 2;
             } else {
                 const int t0 = tensor(q + ".cv1.0", c, sd), t1 = tensor(q + ".cv1.1", 2 * c, sd);
                 const int t2 = tensor(q + ".cv1.2", 2 * c, sd), t3 = tensor(q + ".cv1.3", c, sd);
@@ -157,6 +159,7 @@ struct Builder {
             }
         }
         conv(p + ".cv2", full(Y), out, 1, 1, ACT_SILU);
+        if (m1 >= 0) { e.ops.back().c2f_m1 = m1; e.ops.back().c2f_m2 = m1 + 1; }    // (t and the c slice have no other reader)
     }
     void scdown(const std::string& p, View in, View out) {
         const int t = tensor(p + ".cv1", out.C, sdiv_of(in));
@@ -393,6 +396,7 @@ static int build_graph(yp_engine& e) {
 static ConvParams conv_params(const yp_engine& e, const Op& o);
 static DwPwParams dwpw_params(const yp_engine& e, const Op& c);
 static FrontParams front_params(const yp_engine& e, const Op& o, const uint8_t* img);
+static C2fParams c2f_params(const yp_engine& e, const Op& o);
 static size_t tensor_elem_bytes(const yp_engine& e, const TensorDesc& t) { return (t.f32 || e.dtype == DT_F32) ? 4 : 2; }
 
 static int make_plan(yp_engine& e, int B, int H, int W) {
@@ -434,7 +438,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel", "anchor_max_level_kernel"};
-    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; }
+    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; }
     static const bool no_fold = [] { const char* v = std::getenv("YOLOP_NO_FOLD"); return v && *v == '1'; }();   // A/B switch
     for (auto& o : e.ops) {
         if (o.kind != OP_CONV || o.fold_up < 0 || e.dtype != DT_BF16 || no_fold) continue;
@@ -466,6 +470,11 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
                 continue;
             }
             o.fused2 = false;
+        }
+        static const bool no_c2f = [] { const char* v = std::getenv("YOLOP_NO_C2F"); return v && *v == '1'; }();   // A/B switch
+        if (o.kind == OP_CONV && o.c2f_m1 >= 0 && e.dtype == DT_BF16 && e.fuse && !no_c2f && c2f_fused_valid(c2f_params(e, o))) {
+            o.fused4 = true; e.ops[o.c2f_m1].skip = true; e.ops[o.c2f_m2].skip = true; o.kernel = "c2f_fused_kernel";
+            continue;
         }
         if (o.kind == OP_CONV && o.fuse_dw >= 0 && e.dtype == DT_BF16 && e.fuse) {
             const DwPwParams q = dwpw_params(e, o);
@@ -592,6 +601,24 @@ static FrontParams front_params(const yp_engine& e, const Op& o, const uint8_t* 
     return p;
 }
 
+static C2fParams c2f_params(const yp_engine& e, const Op& o) {
+    const Op &m1 = e.ops[o.c2f_m1], &m2 = e.ops[o.c2f_m2];
+    const WeightDesc &w1 = e.weights[m1.widx], &w2 = e.weights[m2.widx], &w3 = e.weights[o.widx];
+    const TensorDesc &ti = e.tensors[o.in.t], &to = e.tensors[o.out.t];
+    C2fParams p{};
+    p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.x_bytes = ti.bytes; p.B = e.pB; p.H = ti.H; p.W = ti.W; p.C = m1.in.C;
+    p.w1 = w1.d_w; p.bias1 = w1.d_b; p.act1 = m1.act; p.Kpad1 = w1.Kpad; p.w1_bytes = w1.mat_bytes;
+    p.w2 = w2.d_w; p.bias2 = w2.d_b; p.act2 = m2.act; p.Kpad2 = w2.Kpad; p.w2_bytes = w2.mat_bytes;
+    p.shortcut = m2.res.t >= 0 ? 1 : 0;
+    p.w3 = w3.d_w; p.bias3 = w3.d_b; p.act3 = o.act; p.Kpad3 = w3.Kpad; p.Cout = o.out.C; p.w3_bytes = w3.mat_bytes;
+    p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.y_bytes = to.bytes;
+    // the kernel's channel map: a = [coff, coff+C), b = the next C (the bottleneck's input and residual), c = the C after that
+    if (m1.in.t != o.in.t || m1.in.coff != o.in.coff + p.C || m2.out.t != o.in.t || m2.out.coff != o.in.coff + 2 * p.C || o.in.C != 3 * p.C ||
+        m1.k != 3 || m2.k != 3 || m1.s != 1 || m2.s != 1 || m1.out.C != p.C || m2.out.C != p.C || m1.res.t >= 0 ||
+        (m2.res.t >= 0 && (m2.res.t != m1.in.t || m2.res.coff != m1.in.coff)) || (to.f32 && e.dtype == DT_BF16)) p.C = 0;
+    return p;
+}
+
 static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_t st) {
     auto T = [&](const View& v) -> const TensorDesc& { return e.tensors[v.t]; };
     const int B = e.pB;
@@ -607,6 +634,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
         case OP_CONV:
             if (o.fused) return launch_conv_dwpw(dwpw_params(e, o), st);
             if (o.fused3) return launch_frontend(front_params(e, o, a.in), st);
+            if (o.fused4) return launch_c2f_fused(c2f_params(e, o), st);
             if (o.fused2) { const ConvParams q = conv_params(e, o); return launch_conv_halo_s2(q, o.cfg - 500, st); }
             return launch_conv(conv_params(e, o), e.dtype, st);
         case OP_CONVT: {
@@ -730,7 +758,7 @@ static int autotune(yp_engine& e) {
     };
     for (Op& o : e.ops) {
         if (o.kind != OP_CONV && o.kind != OP_CONVT) continue;
-        if (o.fused || o.fused2) continue;
+        if (o.fused || o.fused2 || o.fused4 || o.skip) continue;
         ConvParams p{};
         if (o.kind == OP_CONV) p = conv_params(e, o);
         else { p.Cin = o.in.C; p.Cout = o.out.C; p.ks = 1; p.Kpad = e.weights[o.widx].Kpad; p.M = e.pB * e.tensors[o.in.t].H * e.tensors[o.in.t].W;
@@ -802,7 +830,7 @@ static bool load_tune_cache(yp_engine& e) {
         if (o.kind == OP_CONV || o.kind == OP_CONVT) {
             o.cfg = m[o.name];
             if (o.fused2) { o.cfg = 500 + conv_halo_s2_pw_cfg(conv_params(e, o)); continue; }
-            if (o.kind == OP_CONV && !o.fused) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);   // a fused dw->pw op keeps its own symbol
+            if (o.kind == OP_CONV && !o.fused && !o.fused4) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);   // a fused op keeps its own symbol
         }
     return true;
 }
@@ -858,6 +886,7 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     rd.clear(); wr.clear();
     if (o.skip) return;
     if (o.fused) rd.push_back(e.ops[o.fuse_dw].in);
+    else if (o.fused4) rd.push_back(View{o.in.t, o.in.coff, 2 * e.ops[o.c2f_m1].in.C});
     else if (o.fused3) { /* reads the caller's frames only */ }
     else if (o.fused2) rd.push_back(e.ops[o.fuse_pre].in);
     else if (o.in.t >= 0) rd.push_back(o.in);
