@@ -264,6 +264,7 @@ struct DwPwParams {                              // fused depthwise 3x3 s1 -> po
     const void* w_dw; const float* b_dw; int act_dw;            // depthwise: packed [9][C] bf16, bias fp32
     const void* w_pw; int Kpad; size_t wpw_bytes; const float* b_pw; int act_pw;   // pointwise: packed [Cout^][Kpad]
     void* y; int y_stride, y_coff; size_t y_bytes; int Cout; int out_f32;
+    unsigned long long* clk;                                    // debug (YOLOP_DWPW_CLOCKS=1): per-wave phase clocks, else null
 };
 bool conv_dwpw_valid(const DwPwParams& p);
 const char* conv_dwpw_kernel_name(const DwPwParams& p);

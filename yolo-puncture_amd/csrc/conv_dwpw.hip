@@ -12,6 +12,9 @@
 // (SURVEY.md Appendix A.2/A.4 [U]; run inside `.predict`, reference yolo_seg/app.py:91). Saves one launch and one
 // write + read of the intermediate tensor per pair.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace yp {
 
@@ -23,6 +26,16 @@ __device__ __forceinline__ float silu_q(float x) { return x * __builtin_amdgcn_r
 template <int N> __device__ __forceinline__ void wait_vmq() {
     static_assert(N >= 0 && N < 64, "vmcnt range");
     __builtin_amdgcn_s_waitcnt((N & 0xF) | (7 << 4) | (0xF << 8) | (((N >> 4) & 3) << 14));
+}
+// LDS accesses behind the compiler's back: it cannot tell them from the in-flight LDS-DMA of the next chunk apart and drains
+// vmcnt to 0 in front of them (= no prefetch at all). The caller orders them with explicit lgkmcnt waits.
+__device__ __forceinline__ f32x4 lds_read16_async(const unsigned char* src) {
+    f32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)(const __attribute__((address_space(3))) unsigned char*)src) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_write8(unsigned char* dst, uint2 v) {
+    asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)dst), "v"(*(const unsigned long long*)&v) : "memory");
 }
 __device__ __forceinline__ int qswz(int row) { return ((row >> 2) & 1) << 1; }
 
@@ -186,9 +199,9 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
         f32x4 dacc[RPW][2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const float4 bb = *(const float4*)(Bdw + c * 32 + 16 * h + fc * 4);
+            const f32x4 bb = lds_read16_async((const unsigned char*)(Bdw + c * 32 + 16 * h + fc * 4));
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) dacc[r][h] = f32x4{bb.x, bb.y, bb.z, bb.w};
+            for (int r = 0; r < RPW; ++r) dacc[r][h] = bb;
         }
 #pragma unroll
         for (int hy = 0; hy < RPW + 2; ++hy)
@@ -217,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (__bf16)sv[i];
                 const int c8 = 2 * h + (fc >> 1);
-                *(uint2*)(asl + px * 64 + ((c8 ^ qswz(px)) * 16) + (fc & 1) * 8) = *(const uint2*)o;
+                lds_write8(asl + px * 64 + ((c8 ^ qswz(px)) * 16) + (fc & 1) * 8, *(const uint2*)o);
             }
         }
     };
@@ -277,6 +290,9 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
     };
 
     // ---- skewed pipeline over the flattened (tile, chunk) sequence --------------------------------------------------------
+    unsigned long long clk[4] = {0, 0, 0, 0};
+#define DP_STAMP(i) if (p.clk) { const unsigned long long now = __builtin_amdgcn_s_memtime(); clk[i] += now - last; last = now; }
+    unsigned long long last = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
     int rd_slot = 0, g = 0;
     unsigned epmask = 0;
     bool first = true;
@@ -293,15 +309,19 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
                 __builtin_amdgcn_s_barrier();
             }
             first = false;
+            DP_STAMP(0)
             issue_next();
             epmask <<= 1;
             dw_stage(c, rd_slot, g & 1);
+            DP_STAMP(1)
             if (prev_tile >= 0) {
                 mfma_stage(prev_c, (g - 1) & 1);
+                DP_STAMP(2)
                 if (prev_c == nchunk - 1) {
                     epilogue(prev_tile);
                     reset_acc();
                     epmask |= 1u;
+                    DP_STAMP(3)
                 }
             }
             prev_tile = tile;
@@ -317,6 +337,8 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
         epilogue(prev_tile);
     }
     wait_vmq<0>();
+    if (p.clk && lane == 0)
+        for (int i = 0; i < 4; ++i) p.clk[((size_t)blockIdx.x * NW + wave) * 4 + i] = clk[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -350,7 +372,7 @@ const char* conv_dwpw_kernel_name(const DwPwParams& p) {
 
 template <int BN, bool OUT_F32>
 static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t st) {
-    constexpr int TH = 8, NW = 8;
+    constexpr int TH = 8, NW = 8;       // (16-row tiles - two depthwise rows per wave - measured no faster: 20 % less work per row, lost to tile imbalance)
     const size_t sh = dwpw_lds(TH, BN, p.C);
     const int tiles_h = (p.H + TH - 1) / TH, tiles_w = (p.W + 15) / 16, ntiles = (p.Cout + BN - 1) / BN;
     const int num_tiles = p.B * tiles_h * tiles_w;
@@ -364,6 +386,29 @@ static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) return e;
         attr = true;
+    }
+    static const bool clocks = [] { const char* v = std::getenv("YOLOP_DWPW_CLOCKS"); return v && *v == '1'; }();   // debug: per-phase s_memtime sums
+    if (clocks) {
+        DwPwParams q = p;
+        const size_t n = (size_t)G * ntiles * NW * 4;
+        if (hipMalloc((void**)&q.clk, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+        hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3(NW * 64), sh, st, q, tiles_h, tiles_w, ntiles, G);
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(n);
+        (void)hipMemcpy(h.data(), q.clk, n * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(q.clk);
+        static const char* nm[4] = {"wait+barrier", "issue+dw", "mfma", "epilogue"};
+        const double steps = (double)num_tiles / G * (p.C / 32);
+        for (int w = 0; w < NW; w += NW - 1) {
+            fprintf(stderr, "[dwpw clocks] C=%d Cout=%d %dx%d wave %d, s_memtime ticks per chunk step:", p.C, p.Cout, p.H, p.W, w);
+            for (int i = 0; i < 4; ++i) {
+                double s = 0;
+                for (int g = 0; g < G * ntiles; ++g) s += (double)h[((size_t)g * NW + w) * 4 + i];
+                fprintf(stderr, " %s %.0f", nm[i], s / (G * ntiles) / steps);
+            }
+            fprintf(stderr, "\n");
+        }
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3(NW * 64), sh, st, p, tiles_h, tiles_w, ntiles, G);
     return hipGetLastError();

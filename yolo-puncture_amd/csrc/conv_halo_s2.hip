@@ -232,7 +232,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_s2_kernel(const Conv
                     if (p.act == ACT_SILU) silu4_packed(sv);
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = (__bf16)sv[i];
-                    *(uint2*)(tb + px * 128 + (((co >> 3) ^ ((px >> 1) & 7)) * 16) + (co & 7) * 2) = *(const uint2*)o;
+                    // (asm: a compiler-visible ds_write would first drain vmcnt to 0, i.e. wait for the next tile's halo DMA)
+                    asm volatile("ds_write_b64 %0, %1" ::"v"((unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)(tb + px * 128 + (((co >> 3) ^ ((px >> 1) & 7)) * 16) + (co & 7) * 2)),
+                                 "v"(*(const unsigned long long*)o) : "memory");
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
