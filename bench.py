@@ -180,6 +180,8 @@ def main():
         prof = eng.profile(frames, iters=5)
         by_kernel = {}
         for o in prof:
+            if o["kernel"] == "-":       # work done by a fused consumer: no launch of its own
+                continue
             k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
             k["ms"] += o["ms"]; k["flops"] += o["flops"]; k["bytes"] += o["bytes"]; k["n"] += 1
         total_ms = sum(k["ms"] for k in by_kernel.values())

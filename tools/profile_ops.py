@@ -17,9 +17,12 @@ eng = Engine(a.variant, 80, a.seg, a.dtype, 0, state=synthetic_state(a.variant, 
 im = torch.randint(0, 256, (a.batch, a.imgsz, a.imgsz, 3), dtype=torch.uint8).cuda()
 eng.profile(im, iters=2)
 ops = eng.profile(im, iters=a.iters)
-tot = sum(o["ms"] for o in ops)
+tot = sum(o["ms"] for o in ops if o["kernel"] != "-")
 lines = []
 for o in ops:
+    if o["kernel"] == "-":
+        lines.append(f'{o["name"]:34s} (fused into a later op: no launch)')
+        continue
     ms = max(o["ms"], 1e-6)
     lines.append(f'{o["name"]:34s} {o["kernel"][:38]:38s} {o["ms"]*1e3:8.1f} us {o["flops"]/ms/1e9:8.1f} TF {o["bytes"]/ms/1e6:8.0f} GB/s  {o["flops"]/1e9:7.2f} GF {o["bytes"]/1e6:7.1f} MB')
 lines.append(f"total {tot:.3f} ms  ->  {a.batch/tot*1e3:.0f} img/s (eager, event-timed sum)")

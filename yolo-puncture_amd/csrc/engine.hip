@@ -508,6 +508,34 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         } else if (o.kind == OP_POOL3 && e.dtype == DT_BF16 && (o.in.C & 31) == 0) o.kernel = "sppf_pool3_bf16_kernel";
         else o.kernel = kn[o.kind];
     }
+    // algorithmic work of the graph as it runs: an op whose work moved into a fused consumer reports nothing and launches
+    // nothing; the consumer reports the FLOPs of all its stages and the bytes of what it reads and writes (the intermediates
+    // never reach HBM), a conv with a folded upsample reads the low-resolution tensor instead of its upsampled copy
+    {
+        const double es = e.es();
+        auto vb = [&](const View& v) {
+            if (v.t < 0) return 0.0;
+            const TensorDesc& t = e.tensors[v.t];
+            return (double)B * t.H * t.W * v.C * (double)tensor_elem_bytes(e, t);
+        };
+        auto wb = [&](const Op& q) { const WeightDesc& w = e.weights[q.widx]; return (double)w.cout * w.cin_g * w.k * w.k * es; };
+        for (auto& o : e.ops) {
+            if (o.kind != OP_CONV) continue;
+            if (o.fused) { const Op& d = e.ops[o.fuse_dw]; o.flops += d.flops; o.bytes = vb(d.in) + vb(d.res) + vb(o.out) + wb(d) + wb(o); }
+            else if (o.fused3) {
+                const Op &c1 = e.ops[o.fuse_pre], &st = e.ops[o.stem_op];
+                o.flops += c1.flops + st.flops; o.bytes = (double)B * H * W * 3 + vb(o.out) + wb(st) + wb(c1) + wb(o);
+            } else if (o.fused2) { const Op& c1 = e.ops[o.fuse_pre]; o.flops += c1.flops; o.bytes = vb(c1.in) + vb(o.out) + wb(c1) + wb(o); }
+            else if (o.fused4) {
+                const Op &m1 = e.ops[o.c2f_m1], &m2 = e.ops[o.c2f_m2];
+                o.flops += m1.flops + m2.flops;
+                o.bytes = vb(View{o.in.t, o.in.coff, 2 * m1.in.C}) + vb(o.out) + wb(m1) + wb(m2) + wb(o);
+            }
+            if (o.folded) { const Op& u = e.ops[o.fold_up]; o.bytes += vb(u.in) - vb(u.out); }
+        }
+        for (auto& o : e.ops)
+            if (o.skip) { o.flops = 0; o.bytes = 0; o.kernel = "-"; }
+    }
     return YP_OK;
 }
 
@@ -830,7 +858,7 @@ static bool load_tune_cache(yp_engine& e) {
         if (o.kind == OP_CONV || o.kind == OP_CONVT) {
             o.cfg = m[o.name];
             if (o.fused2) { o.cfg = 500 + conv_halo_s2_pw_cfg(conv_params(e, o)); continue; }
-            if (o.kind == OP_CONV && !o.fused && !o.fused4) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);   // a fused op keeps its own symbol
+            if (o.kind == OP_CONV && !o.fused && !o.fused4 && !o.skip) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);   // a fused op keeps its own symbol
         }
     return true;
 }
