@@ -150,7 +150,18 @@ __device__ void select_topk_sorted(const unsigned long long* keys, int n, int k,
         const unsigned long long pre = S.prefix;
         for (int i = tid; i < n; i += HT) {
             const unsigned long long key = keys[i];
-            if (pass == 0 || (key >> (shift + 8)) == pre) atomicAdd(&S.hist[(unsigned)(key >> shift) & 255u], 1u);
+            const unsigned bin = (unsigned)(key >> shift) & 255u;
+            // wave-aggregated counting: scores crowd into a few exponent bins (and tie-heavy inputs into one bin per pass), where
+            // per-lane LDS atomics serialise; up to 4 rounds peel the bin of the first pending lane, stragglers go one by one
+            unsigned long long pend = __ballot(pass == 0 || (key >> (shift + 8)) == pre);
+            for (int r = 0; r < 4 && pend; ++r) {
+                const int leader = __ffsll((long long)pend) - 1;
+                const unsigned lb = (unsigned)__shfl((int)bin, leader, 64);
+                const unsigned long long same = __ballot(bin == lb) & pend;
+                if ((int)(threadIdx.x & 63) == leader) atomicAdd(&S.hist[lb], (unsigned)__popcll(same));
+                pend &= ~same;
+            }
+            if ((pend >> (threadIdx.x & 63)) & 1ull) atomicAdd(&S.hist[bin], 1u);
         }
         __syncthreads();
         if (tid < 64) {   // one wave: find the bin holding the want-th largest key among the keys that match the prefix
