@@ -136,6 +136,7 @@ struct FrontParams {
     const void* w1; const float* bias1; int act1, C1, Kpad1; size_t w1_bytes;   // 3x3 s2: packed [C1^][9*C0]
     const void* w2; const float* bias2; int act2, C2, Kpad2; size_t w2_bytes;   // 1x1:    packed [C2^][C1]
     void* y; int y_stride, y_coff; size_t y_bytes; int Ho, Wo;           // final output view (Ho x Wo = H1/2 x W1/2)
+    unsigned long long* clk;                                              // debug (YOLOP_FRONT_CLOCKS=1): per-wave stage clocks, else null
 };
 bool frontend_valid(const FrontParams& p);
 hipError_t launch_frontend(const FrontParams& p, hipStream_t st);

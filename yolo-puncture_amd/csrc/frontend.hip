@@ -13,6 +13,10 @@
 // Rounding points are those of the three separate kernels (each intermediate is rounded to bf16 exactly where the unfused
 // graph stores it), so the result differs from the unfused engine only by fp32 summation order inside a stage.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <type_traits>
 
 namespace yp {
 
@@ -172,6 +176,9 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
 #pragma unroll
     for (int h = 0; h < 2; ++h) { const int r = h * 16 + fr; w0f[h] = *(const bf16x8*)(W0s + r * 64 + ((fc ^ fswz(r)) * 16)); }
 
+    unsigned long long clk[6] = {0, 0, 0, 0, 0, 0};
+#define FE_STAMP(i) if (p.clk) { const unsigned long long now = __builtin_amdgcn_s_memtime(); clk[i] += now - last; last = now; }
+    unsigned long long last = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
     for (; tile < num_tiles; tile += G) {
         int t = tile;
         const int tw = t % tiles_w; t /= tiles_w;
@@ -189,26 +196,50 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
             if (two) { blive = patch_px(nt, tid + 512, bb_, bsy, bsx); fe_load(p, irs, bb_, bsy, bsx, blive, rb); }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FE_STAMP(0)
         __builtin_amdgcn_s_barrier();
+        FE_STAMP(5)
         // ---- B: stem GEMM + SiLU into the halo image ------------------------------------------------------------------------
-        for (int f = wave; f < FE_HPAD / 16; f += FE_NW) {
-            const int hp = f * 16 + fr;
-            const bf16x8 xf = *(const bf16x8*)(Ib + hp * 64 + ((fc ^ fswz(hp)) * 16));
-            const bool in = Vs[hp] != 0;                  // else model.1's zero padding
+        // (36 pixel fragments over 8 waves: four each as one batch - all operand reads, then the 8 MFMAs, then the epilogues, so the
+        //  LDS / MFMA / transcendental latencies overlap across fragments instead of adding up per fragment - and a fifth for waves 0-3)
+        auto stem_frags = [&](auto NFC, int f0) {
+            constexpr int NF = decltype(NFC)::value;
+            bf16x8 xf[NF];
+            bool in[NF];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                f32x4 acc = {bias0[h].x, bias0[h].y, bias0[h].z, bias0[h].w};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0f[h], xf, acc, 0, 0, 0);
-                __attribute__((aligned(8))) __bf16 o[4];
-                float sv[4] = {acc[0], acc[1], acc[2], acc[3]};
-                if (p.act0 == ACT_SILU) silu4(sv);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = (__bf16)(in ? sv[i] : 0.f);
-                if (hp < FE_HP) *(uint2*)(Hs + hp * 64 + (((2 * h + (fc >> 1)) ^ fswz(hp)) * 16) + (fc & 1) * 8) = *(const uint2*)o;
+            for (int j = 0; j < NF; ++j) {
+                const int hp = (f0 + j * FE_NW) * 16 + fr;
+                xf[j] = *(const bf16x8*)(Ib + hp * 64 + ((fc ^ fswz(hp)) * 16));
+                in[j] = Vs[hp] != 0;                      // else model.1's zero padding
             }
-        }
+            f32x4 acc[NF][2];
+#pragma unroll
+            for (int j = 0; j < NF; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    acc[j][h] = f32x4{bias0[h].x, bias0[h].y, bias0[h].z, bias0[h].w};
+                    acc[j][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w0f[h], xf[j], acc[j][h], 0, 0, 0);
+                }
+#pragma unroll
+            for (int j = 0; j < NF; ++j) {
+                const int hp = (f0 + j * FE_NW) * 16 + fr;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    __attribute__((aligned(8))) __bf16 o[4];
+                    float sv[4] = {acc[j][h][0], acc[j][h][1], acc[j][h][2], acc[j][h][3]};
+                    if (p.act0 == ACT_SILU) silu4(sv);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = (__bf16)(in[j] ? sv[i] : 0.f);
+                    if (hp < FE_HP) *(uint2*)(Hs + hp * 64 + (((2 * h + (fc >> 1)) ^ fswz(hp)) * 16) + (fc & 1) * 8) = *(const uint2*)o;
+                }
+            }
+        };
+        stem_frags(std::integral_constant<int, 4>{}, wave);
+        if (wave < FE_HPAD / 16 - 4 * FE_NW) stem_frags(std::integral_constant<int, 1>{}, wave + 4 * FE_NW);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FE_STAMP(1)
         __builtin_amdgcn_s_barrier();
+        FE_STAMP(5)
         // ---- C: model.1 (3x3 s2 over the E/O-plane image) ---------------------------------------------------------------------
         f32x4 acc[FN][FM];
 #pragma unroll
@@ -247,7 +278,9 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
             }
         }
         // ---- D: model.2.cv1 on the tile (intermediate through the halo image's memory) ------------------------------------------
+        FE_STAMP(2)
         __builtin_amdgcn_s_barrier();                     // every wave is done reading the halo image
+        FE_STAMP(5)
 #pragma unroll
         for (int r = 0; r < FM; ++r) {
             const int px = (wm * FM + r) * 16 + fr;
@@ -263,7 +296,9 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FE_STAMP(3)
         __builtin_amdgcn_s_barrier();
+        FE_STAMP(5)
 #pragma unroll
         for (int a = 0; a < FN; ++a)
 #pragma unroll
@@ -303,9 +338,12 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
                 __builtin_amdgcn_raw_buffer_store_b64(*(const __attribute__((ext_vector_type(2))) unsigned*)o, yrs, off, 0, 0);
             }
         }
+        FE_STAMP(4)
         // (the next tile's stage A writes Ib, which stage B of this tile finished with two barriers ago; its stage B writes the
         //  halo image only after the barrier that follows stage A, which every wave reaches after its stage-D reads)
     }
+    if (p.clk && lane == 0)
+        for (int i = 0; i < 6; ++i) p.clk[((size_t)blockIdx.x * FE_NW + wave) * 6 + i] = clk[i];
 }
 
 static size_t frontend_lds() { return (size_t)2 * FE_HB + 9 * 64 * 64 + 64 * 128 + 32 * 64 + 1024; }
@@ -331,6 +369,29 @@ hipError_t launch_frontend(const FrontParams& p, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void*)frontend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) return e;
         attr = true;
+    }
+    static const bool clocks = [] { const char* v = std::getenv("YOLOP_FRONT_CLOCKS"); return v && *v == '1'; }();   // debug: per-stage s_memtime sums
+    if (clocks) {
+        FrontParams q = p;
+        const size_t n = (size_t)G * FE_NW * 6;
+        if (hipMalloc((void**)&q.clk, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+        hipLaunchKernelGGL(frontend_kernel, dim3(G), dim3(FE_NW * 64), sh, st, q, tiles_h, tiles_w, G);
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(n);
+        (void)hipMemcpy(h.data(), q.clk, n * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(q.clk);
+        static const char* nm[6] = {"A im2col", "B stem", "C 3x3s2", "D silu->lds", "E 1x1+store", "barriers"};
+        const double tiles_per = (double)num_tiles / G;
+        for (int w = 0; w < FE_NW; w += FE_NW - 1) {
+            fprintf(stderr, "[frontend clocks] wave %d, s_memtime ticks per tile:", w);
+            for (int i = 0; i < 6; ++i) {
+                double s = 0;
+                for (int g = 0; g < G; ++g) s += (double)h[((size_t)g * FE_NW + w) * 6 + i];
+                fprintf(stderr, " %s %.0f", nm[i], s / G / tiles_per);
+            }
+            fprintf(stderr, "\n");
+        }
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(frontend_kernel, dim3(G), dim3(FE_NW * 64), sh, st, p, tiles_h, tiles_w, G);
     return hipGetLastError();
