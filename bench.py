@@ -175,44 +175,50 @@ def main():
 
     roof = None
     if rank == 0 and not a.no_roofline:
-        # per-op HIP event pairs on the launch stream (eager replay of the same plan), after the timed region
-        eng.set_graph(False)
-        prof = eng.profile(frames, iters=5)
-        by_kernel = {}
-        for o in prof:
-            if o["kernel"] == "-":       # work done by a fused consumer: no launch of its own
-                continue
-            k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
-            k["ms"] += o["ms"]; k["flops"] += o["flops"]; k["bytes"] += o["bytes"]; k["n"] += 1
-        total_ms = sum(k["ms"] for k in by_kernel.values())
-        dom = max(by_kernel, key=lambda n: by_kernel[n]["ms"])      # the single device symbol with the most time
-        d = by_kernel[dom]
-        ai = d["flops"] / max(d["bytes"], 1.0)
-        peak_tf = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
-        ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
-        avg_ms = d["ms"] / d["n"]
-        traffic = measured_traffic(dom)
-        if ai >= ridge:
-            ach = d["flops"] / d["n"] / (avg_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak_tf, unit="TFLOP/s", frac=round(ach / peak_tf, 4), traffic=traffic)
-        else:
-            ach = d["bytes"] / d["n"] / (avg_ms * 1e-3) / 1e9
-            roof = dict(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic)
-        # the conv family as a whole (all instantiations of the LDS-DMA MFMA conv kernels), for orientation
-        fam = [v for n, v in by_kernel.items() if n.startswith("conv_")]
-        fam_ms, fam_fl, fam_by = sum(v["ms"] for v in fam), sum(v["flops"] for v in fam), sum(v["bytes"] for v in fam)
-        roof.update(kernel=dom, launches_per_step=d["n"], avg_launch_ms=round(avg_ms, 5),
-                    alg_bytes_per_launch=round(d["bytes"] / d["n"]), alg_flops_per_launch=round(d["flops"] / d["n"]),
-                    flop_per_byte=round(ai, 1), tflops=round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
-                    share_of_step=round(d["ms"] / total_ms, 3), eager_step_ms=round(total_ms, 3),
-                    conv_family=dict(ms=round(fam_ms, 4), share_of_step=round(fam_ms / total_ms, 3),
-                                     tflops=round(fam_fl / max(fam_ms, 1e-9) / 1e9, 1), gbs=round(fam_by / max(fam_ms, 1e-9) / 1e6, 0)),
-                    kernels={n: dict(ms=round(v["ms"], 4), n=v["n"], tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
-                                     gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)) for n, v in by_kernel.items()})
+        try:
+            # per-op HIP event pairs on the launch stream (eager replay of the same plan), after the timed region
+            eng.set_graph(False)
+            prof = eng.profile(frames, iters=5)
+            by_kernel = {}
+            for o in prof:
+                if o["kernel"] == "-":       # work done by a fused consumer: no launch of its own
+                    continue
+                k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+                k["ms"] += o["ms"]; k["flops"] += o["flops"]; k["bytes"] += o["bytes"]; k["n"] += 1
+            total_ms = sum(k["ms"] for k in by_kernel.values())
+            dom = max(by_kernel, key=lambda n: by_kernel[n]["ms"])      # the single device symbol with the most time
+            d = by_kernel[dom]
+            ai = d["flops"] / max(d["bytes"], 1.0)
+            peak_tf = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+            ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+            avg_ms = d["ms"] / d["n"]
+            traffic = measured_traffic(dom)
+            if ai >= ridge:
+                ach = d["flops"] / d["n"] / (avg_ms * 1e-3) / 1e12
+                roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak_tf, unit="TFLOP/s", frac=round(ach / peak_tf, 4), traffic=traffic)
+            else:
+                ach = d["bytes"] / d["n"] / (avg_ms * 1e-3) / 1e9
+                roof = dict(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4), traffic=traffic)
+            # the conv family as a whole (all instantiations of the LDS-DMA MFMA conv kernels), for orientation
+            fam = [v for n, v in by_kernel.items() if n.startswith("conv_")]
+            fam_ms, fam_fl, fam_by = sum(v["ms"] for v in fam), sum(v["flops"] for v in fam), sum(v["bytes"] for v in fam)
+            roof.update(kernel=dom, launches_per_step=d["n"], avg_launch_ms=round(avg_ms, 5),
+                        alg_bytes_per_launch=round(d["bytes"] / d["n"]), alg_flops_per_launch=round(d["flops"] / d["n"]),
+                        flop_per_byte=round(ai, 1), tflops=round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
+                        share_of_step=round(d["ms"] / total_ms, 3), eager_step_ms=round(total_ms, 3),
+                        conv_family=dict(ms=round(fam_ms, 4), share_of_step=round(fam_ms / total_ms, 3),
+                                         tflops=round(fam_fl / max(fam_ms, 1e-9) / 1e9, 1), gbs=round(fam_by / max(fam_ms, 1e-9) / 1e6, 0)),
+                        kernels={n: dict(ms=round(v["ms"], 4), n=v["n"], tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
+                                         gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)) for n, v in by_kernel.items()})
+        except Exception as ex:      # (a failed diagnostic pass must not cost the measured line)
+            roof = {"error": f"{type(ex).__name__}: {ex}"}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.variant, a.seg, S, a.cpu_frames)
+        try:
+            cpu = cpu_baseline(a.variant, a.seg, S, a.cpu_frames)
+        except Exception as ex:          # the timed result above stands on its own: report the failure instead of losing the line
+            cpu = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
         line = {

@@ -137,14 +137,22 @@ struct SelectShared {
 // Radix select from the top byte down; it stops as soon as the bin that holds the k-th key is wanted whole (then the
 // threshold is the smallest key with that prefix) - in practice after the score bytes. The <= 512 survivors are ordered
 // by rank counting (two threads per key, broadcast LDS reads) instead of a barrier-bound sorting network.
+// `nflat`: exclusive bound of the flat indices in the keys' low words (0xFFFFFFFF - flat): the index bytes every key shares
+// (0xFF above the bound's top bit) need no counting pass.
 __device__ void select_topk_sorted(const unsigned long long* keys, int n, int k, unsigned long long* out512, unsigned long long* tmp512,
-                                   SelectShared& S) {
+                                   SelectShared& S, unsigned nflat) {
     const int tid = threadIdx.x;
     if (tid == 0) { S.prefix = 0ull; S.want = (unsigned)k; S.count = 0xFFFFFFFFu; }
     __syncthreads();
     unsigned long long kth = 0ull;
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 56 - 8 * pass;
+        if (pass >= 4 && ((nflat - 1u) >> shift) == 0u) {      // every key has 0xFF here (block-uniform branch)
+            __syncthreads();                                    // (everyone has taken its copy of the previous prefix)
+            kth = (kth << 8) | 0xFFull;
+            if (tid == 0) S.prefix = kth;
+            continue;
+        }
         if (tid < 256) S.hist[tid] = 0;
         __syncthreads();
         const unsigned long long pre = S.prefix;
@@ -242,7 +250,7 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
     }
     __syncthreads();
     HEAD_STAMP(1);
-    select_topk_sorted(keys, A, k, best, tmp, S);
+    select_topk_sorted(keys, A, k, best, tmp, S, (unsigned)A);
     HEAD_STAMP(2);
     for (int r = tid; r < k; r += HT) {
         const int a = (int)(0xFFFFFFFFu - (unsigned)(best[r] & 0xFFFFFFFFull));
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
         HEAD_STAMP(3);
         const int n = (int)nfill;
         const int kk = min(k, n);
-        select_topk_sorted(keys, n, kk, best, tmp, S);
+        select_topk_sorted(keys, n, kk, best, tmp, S, (unsigned)(A * p.nc));
         for (int i = tid; i < kk; i += HT) carry[i] = best[i];
         have = kk;
         __syncthreads();
