@@ -258,6 +258,8 @@ hipError_t launch_letterbox(const uint8_t* src, int h0, int w0, uint8_t* dst, in
                             int left, int pad, hipStream_t st);
 size_t head_scratch_bytes(int B, int A);
 hipError_t head_read_clocks(unsigned long long* out8);
+hipError_t launch_copy_out(const float* det, float* det_out, const int32_t* idx, int32_t* idx_out, const float* coeff, float* coeff_out,
+                           size_t rows, hipStream_t st);
 hipError_t launch_anchor_max_level(const float* cls, int B, int HW, int nc, unsigned* out, hipStream_t st);
 
 struct DwPwParams {                              // fused depthwise 3x3 s1 -> pointwise 1x1 (conv_dwpw.hip)

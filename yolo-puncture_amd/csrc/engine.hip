@@ -1350,9 +1350,7 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     HIPCHK(hipGraphLaunch(e->gexec, e->own_stream));
     {
         const size_t rows = (size_t)B * e->desc.max_det;
-        HIPCHK(hipMemcpyAsync(det_out, e->o_det, rows * 6 * sizeof(float), hipMemcpyDeviceToDevice, e->own_stream));
-        if (idx_out) HIPCHK(hipMemcpyAsync(idx_out, e->o_idx, rows * sizeof(int32_t), hipMemcpyDeviceToDevice, e->own_stream));
-        if (coeff_out && seg) HIPCHK(hipMemcpyAsync(coeff_out, e->o_coeff, rows * 32 * sizeof(float), hipMemcpyDeviceToDevice, e->own_stream));
+        HIPCHK(launch_copy_out(e->o_det, det_out, e->o_idx, idx_out, e->o_coeff, (coeff_out && seg) ? coeff_out : nullptr, rows, e->own_stream));
     }
     HIPCHK(hipEventRecord(e->ev_out, e->own_stream));
     HIPCHK(hipStreamWaitEvent(st, e->ev_out, 0));

@@ -606,4 +606,29 @@ hipError_t launch_upsample(const UpParams& p, int dtype, hipStream_t st) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// The forward's results leave the engine-owned buffers in ONE launch (instead of up to three device-to-device memcpy
+// commands behind the graph replay): dword copies of det [rows,6], idx [rows] and coeff [rows,32]; null destinations skip.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void copy_out_kernel(const unsigned* __restrict__ s0, unsigned* __restrict__ d0, unsigned n0,
+                                                       const unsigned* __restrict__ s1, unsigned* __restrict__ d1, unsigned n1,
+                                                       const unsigned* __restrict__ s2, unsigned* __restrict__ d2, unsigned n2) {
+    unsigned i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n0) { d0[i] = s0[i]; return; }
+    i -= n0;
+    if (i < n1) { d1[i] = s1[i]; return; }
+    i -= n1;
+    if (i < n2) d2[i] = s2[i];
+}
+
+hipError_t launch_copy_out(const float* det, float* det_out, const int32_t* idx, int32_t* idx_out, const float* coeff, float* coeff_out,
+                           size_t rows, hipStream_t st) {
+    const unsigned n0 = det_out ? (unsigned)(rows * 6) : 0u, n1 = idx_out ? (unsigned)rows : 0u, n2 = coeff_out ? (unsigned)(rows * 32) : 0u;
+    const unsigned total = n0 + n1 + n2;
+    if (total == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_out_kernel, dim3((total + 255u) / 256u), dim3(256), 0, st, (const unsigned*)det, (unsigned*)det_out, n0,
+                       (const unsigned*)idx, (unsigned*)idx_out, n1, (const unsigned*)coeff, (unsigned*)coeff_out, n2);
+    return hipGetLastError();
+}
+
 }  // namespace yp
