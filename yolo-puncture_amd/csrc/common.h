@@ -81,6 +81,8 @@ struct Op {
     bool folded = false;          // plan decision: the upsample is folded into this conv's input gather
     int c2f_m1 = -1, c2f_m2 = -1; // OP_CONV 1x1 closing a C2f with one plain bottleneck: indices of the bottleneck's two 3x3 convs
     bool fused4 = false;          // plan decision: both 3x3 convs and this 1x1 run as c2f_fused_kernel
+    int scd_pre = -1;             // OP_DWCONV 3x3 s2 closing an SCDown: index of the 1x1 conv in front of it
+    bool fused5 = false;          // plan decision: that 1x1 and this depthwise conv run as scdown_fused_kernel
     int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
 };
 
@@ -153,6 +155,17 @@ struct C2fParams {
     unsigned long long* clk;                                              // debug (YOLOP_C2F_CLOCKS=1): per-wave stage clocks, else null
 };
 bool c2f_fused_valid(const C2fParams& p);
+
+// fused SCDown (scdown_fused.hip): 1x1 conv + act -> depthwise 3x3 stride 2
+struct ScdParams {
+    const void* x; int x_stride, x_coff; size_t x_bytes; int B, H, W, K;          // input view [B,H,W,K]
+    const void* w1; const float* bias1; int act1, Kpad1, C; size_t w1_bytes;        // 1x1: packed [C^][K]
+    const void* wd; const float* biasd; int actd;                                    // depthwise 3x3 s2: packed [9][C] bf16, bias fp32
+    void* y; int y_stride, y_coff; size_t y_bytes; int Ho, Wo;
+    unsigned long long* clk;                                                          // debug (YOLOP_SCD_CLOCKS=1), else null
+};
+bool scdown_fused_valid(const ScdParams& p);
+hipError_t launch_scdown_fused(const ScdParams& p, hipStream_t st);
 hipError_t launch_c2f_fused(const C2fParams& p, hipStream_t st);
 
 struct PoolParams {

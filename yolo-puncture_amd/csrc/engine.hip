@@ -165,6 +165,7 @@ struct Builder {
         const int t = tensor(p + ".cv1", out.C, sdiv_of(in));
         conv(p + ".cv1", in, full(t), 1, 1, ACT_SILU);
         dwconv(p + ".cv2", full(t), out, 3, 2, ACT_NONE);
+        e.ops.back().scd_pre = (int)e.ops.size() - 2;                 // (t has no other reader)
     }
     void sppf(const std::string& p, View in, View out) {
         const int c_ = in.C / 2, sd = sdiv_of(in);
@@ -397,6 +398,7 @@ static ConvParams conv_params(const yp_engine& e, const Op& o);
 static DwPwParams dwpw_params(const yp_engine& e, const Op& c);
 static FrontParams front_params(const yp_engine& e, const Op& o, const uint8_t* img);
 static C2fParams c2f_params(const yp_engine& e, const Op& o);
+static ScdParams scd_params(const yp_engine& e, const Op& o);
 static size_t tensor_elem_bytes(const yp_engine& e, const TensorDesc& t) { return (t.f32 || e.dtype == DT_F32) ? 4 : 2; }
 
 static int make_plan(yp_engine& e, int B, int H, int W) {
@@ -438,7 +440,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel", "anchor_max_level_kernel"};
-    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; }
+    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; o.fused5 = false; }
     static const bool no_fold = [] { const char* v = std::getenv("YOLOP_NO_FOLD"); return v && *v == '1'; }();   // A/B switch
     for (auto& o : e.ops) {
         if (o.kind != OP_CONV || o.fold_up < 0 || e.dtype != DT_BF16 || no_fold) continue;
@@ -487,6 +489,11 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
             p.Kpad = (o.in.C + 31) / 32 * 32; p.cfg = o.cfg;
             o.kernel = conv_kernel_name(p, e.dtype);
         } else if (o.kind == OP_DWCONV) {
+            static const bool no_scd = [] { const char* v = std::getenv("YOLOP_NO_SCD"); return v && *v == '1'; }();   // A/B switch
+            if (o.scd_pre >= 0 && e.dtype == DT_BF16 && e.fuse && !no_scd && scdown_fused_valid(scd_params(e, o))) {
+                o.fused5 = true; e.ops[o.scd_pre].skip = true; o.kernel = "scdown_fused_kernel";
+                continue;
+            }
             const char* t = e.dtype == DT_BF16 ? "bf16" : "f32";
             char buf[64];
             DwParams q{};
@@ -520,6 +527,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         };
         auto wb = [&](const Op& q) { const WeightDesc& w = e.weights[q.widx]; return (double)w.cout * w.cin_g * w.k * w.k * es; };
         for (auto& o : e.ops) {
+            if (o.kind == OP_DWCONV && o.fused5) { const Op& c1 = e.ops[o.scd_pre]; o.flops += c1.flops; o.bytes = vb(c1.in) + vb(o.out) + wb(c1) + wb(o); }
             if (o.kind != OP_CONV) continue;
             if (o.fused) { const Op& d = e.ops[o.fuse_dw]; o.flops += d.flops; o.bytes = vb(d.in) + vb(d.res) + vb(o.out) + wb(d) + wb(o); }
             else if (o.fused3) {
@@ -647,6 +655,21 @@ static C2fParams c2f_params(const yp_engine& e, const Op& o) {
     return p;
 }
 
+static ScdParams scd_params(const yp_engine& e, const Op& o) {
+    const Op& c1 = e.ops[o.scd_pre];
+    const WeightDesc &w1 = e.weights[c1.widx], &wd = e.weights[o.widx];
+    const TensorDesc &ti = e.tensors[c1.in.t], &to = e.tensors[o.out.t];
+    ScdParams p{};
+    p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = c1.in.coff; p.x_bytes = ti.bytes; p.B = e.pB; p.H = ti.H; p.W = ti.W; p.K = c1.in.C;
+    p.w1 = w1.d_w; p.bias1 = w1.d_b; p.act1 = c1.act; p.Kpad1 = w1.Kpad; p.C = c1.out.C; p.w1_bytes = w1.mat_bytes;
+    p.wd = wd.d_w; p.biasd = wd.d_b; p.actd = o.act;
+    p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.y_bytes = to.bytes; p.Ho = to.H; p.Wo = to.W;
+    // the kernel's assumptions beyond the sizes: plain 1x1 s1 -> 3x3 s2 over the 1x1's whole output, no residuals, no gather
+    if (c1.k != 1 || c1.s != 1 || c1.res.t >= 0 || o.k != 3 || o.s != 2 || o.res.t >= 0 || o.gs != 0 || o.in.t != c1.out.t ||
+        o.in.coff != c1.out.coff || o.in.C != c1.out.C || o.out.C != c1.out.C || c1.fold_up >= 0 || to.f32) p.K = 0;
+    return p;
+}
+
 static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_t st) {
     auto T = [&](const View& v) -> const TensorDesc& { return e.tensors[v.t]; };
     const int B = e.pB;
@@ -684,6 +707,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             return hipSuccess;
         }
         case OP_DWCONV: {
+            if (o.fused5) return launch_scdown_fused(scd_params(e, o), st);
             const WeightDesc& w = e.weights[o.widx];
             const TensorDesc &ti = T(o.in), &to = T(o.out);
             DwParams p{};
@@ -914,6 +938,7 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     rd.clear(); wr.clear();
     if (o.skip) return;
     if (o.fused) rd.push_back(e.ops[o.fuse_dw].in);
+    else if (o.fused5) rd.push_back(e.ops[o.scd_pre].in);
     else if (o.fused4) rd.push_back(View{o.in.t, o.in.coff, 2 * e.ops[o.c2f_m1].in.C});
     else if (o.fused3) { /* reads the caller's frames only */ }
     else if (o.fused2) rd.push_back(e.ops[o.fuse_pre].in);
