@@ -154,3 +154,26 @@ def test_yolo_constructor_errors(tmp_path):
         y.model.to("cpu")                            # the engine is GPU-only; nothing falls back
     with pytest.raises(ValueError):
         y.predict(None)
+
+
+def test_min_area_rect_len():
+    """shaft length from a polygon (reference yolo_seg/utils/mask_tools.py:12-22): exact on rectangles with integer corners"""
+    # a 10 x 5 rectangle rotated by atan(3/4), corners listed out of order plus interior / edge points
+    pts = [(0, 0), (8, 6), (5, 10), (-3, 4), (4, 3), (1, 5), (2, 4)]
+    length, ratio = hostops.get_coord_min_rect_len(np.asarray(pts, dtype=np.float32))
+    assert abs(length - 10.0) < 1e-9 and abs(ratio - 2.0) < 1e-9
+    # axis-aligned box from a traced contour (what masks.xy holds), float coordinates are truncated like the reference does
+    m = np.zeros((20, 30), bool)
+    m[3:8, 4:21] = True
+    poly = hostops.largest_external_contour(m).astype(np.float32) + 0.7
+    length, ratio = hostops.get_coord_min_rect_len(poly)
+    assert (length, ratio) == (16.0, 4.0)
+    # degenerate inputs
+    assert hostops.get_coord_min_rect_len(np.zeros((2, 2), np.float32)) == (0, 0)
+    assert hostops.get_coord_min_rect_len(np.asarray([(0, 0), (3, 4), (6, 8)], np.float32)) == (10.0, 10.0)    # collinear: width counted as 1
+    # a rotation cannot make the rectangle larger than the axis-aligned bounding box
+    rng = np.random.default_rng(0)
+    cloud = rng.integers(0, 200, size=(300, 2))
+    length, ratio = hostops.get_coord_min_rect_len(cloud)
+    bw, bh = np.ptp(cloud[:, 0]), np.ptp(cloud[:, 1])
+    assert length * (length / ratio) <= bw * bh + 1e-6

@@ -196,3 +196,56 @@ def largest_external_contour(mask: np.ndarray) -> np.ndarray:
         if poly.shape[0] > best.shape[0]:
             best = poly
     return best
+
+
+# ---- shaft length from a polygon (reference yolo_seg/utils/mask_tools.py:12-22, which calls cv2.minAreaRect) ---------------------
+def _convex_hull(pts: np.ndarray) -> np.ndarray:
+    """Andrew's monotone chain on integer points; counter-clockwise, no collinear points, float64 out."""
+    p = np.unique(pts.astype(np.int64), axis=0)            # sorted by x, then y
+    if p.shape[0] <= 2:
+        return p.astype(np.float64)
+
+    def half(seq):
+        h = []
+        for q in seq:
+            while len(h) >= 2 and (h[-1][0] - h[-2][0]) * (q[1] - h[-2][1]) - (h[-1][1] - h[-2][1]) * (q[0] - h[-2][0]) <= 0:
+                h.pop()
+            h.append(q)
+        return h
+
+    lo, up = half(list(map(tuple, p))), half(list(map(tuple, p[::-1])))
+    return np.asarray(lo[:-1] + up[:-1], dtype=np.float64)
+
+
+def min_area_rect_size(points) -> Tuple[float, float]:
+    """(long side, short side) of the minimum-area enclosing rectangle of integer points: one side of that rectangle is collinear
+    with an edge of the convex hull (rotating calipers; the public algorithm behind cv2.minAreaRect, here in float64)."""
+    hull = _convex_hull(np.asarray(points).reshape(-1, 2))
+    n = hull.shape[0]
+    if n == 0 or n == 1:
+        return 0.0, 0.0
+    if n == 2:
+        return float(np.hypot(*(hull[1] - hull[0]))), 0.0
+    best = None
+    for i in range(n):
+        e = hull[(i + 1) % n] - hull[i]
+        u = e / np.hypot(e[0], e[1])
+        v = np.array([-u[1], u[0]])
+        a, b = hull @ u, hull @ v
+        w, h = a.max() - a.min(), b.max() - b.min()
+        if best is None or w * h < best[0]:
+            best = (w * h, w, h)
+    return float(max(best[1], best[2])), float(min(best[1], best[2]))
+
+
+def get_coord_min_rect_len(coord_xy) -> Tuple[float, float]:
+    """Drop-in for the reference's `get_coord_min_rect_len(results[0].masks.xy[i])` (yolo_seg/app.py:101-103): the polygon is
+    truncated to int32 like there; -> (length of the longer side in pixels, length / shorter side, with a zero width counted as 1);
+    (0, 0) for fewer than 3 points."""
+    points = np.array(coord_xy, dtype=np.int32).reshape((-1, 2))
+    if len(points) < 3:
+        return 0, 0
+    length, width = min_area_rect_size(points)
+    if width == 0:
+        width = 1
+    return length, length / width
