@@ -109,6 +109,7 @@ struct ConvParams {
     // fused trailing 1x1 (conv_halo_s2 PW2 form): y = act2(W2 . act(conv(x)) + bias2); Cout is then the intermediate width,
     // y / y_stride / y_coff / y_bytes describe the FINAL output of C2 channels
     const void* w2; const float* bias2; int C2, act2, Kpad2; size_t w2_bytes;
+    unsigned long long* clk;                    // debug (YOLOP_LC_CLOCKS=1, conv_dma_lc only): per-wave phase clocks, else null
 };
 
 struct DwParams {

@@ -14,6 +14,9 @@
 // reached barrier(g). Loaders have nothing but LDS-DMA on their vector-memory queue, so the wait is vmcnt((NS-2)*pieces per stage);
 // consumers have nothing but their own stores and never wait for them inside the loop.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
 
 namespace yp {
 
@@ -148,15 +151,22 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_dma_lc_kernel(cons
         };
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s) issue_next();
+        unsigned long long clk[3] = {0, 0, 0}, last = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
+#define LC_STAMP(i) if (p.clk) { const unsigned long long now = __builtin_amdgcn_s_memtime(); clk[i] += now - last; last = now; }
         for (int tile = j0; tile < mtiles; tile += G) {
             for (int kt = 0; kt < nk; ++kt) {
                 if (lw < FULL) wait_vml<(NS - 2) * MAXP>();   // this wave's pieces of stage g have landed
                 else wait_vml<(NS - 2) * (MAXP - 1)>();
+                LC_STAMP(0)
                 __builtin_amdgcn_s_barrier();          // barrier(g): stage g is published, slot of stage g-1 is free
+                LC_STAMP(1)
                 issue_next();                          // stage g+NS-1
+                LC_STAMP(2)
             }
         }
         wait_vml<0>();
+        if (p.clk && lane == 0)
+            for (int i = 0; i < 3; ++i) p.clk[((size_t)blockIdx.x * (NC + NL) + wave) * 3 + i] = clk[i];
         return;
     }
 
@@ -180,13 +190,16 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_dma_lc_kernel(cons
     }
     f32x4 acc[FN][FM];
     int rslot = 0;
+    unsigned long long clk[3] = {0, 0, 0}, last = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
     for (int tile = j0; tile < mtiles; tile += G) {
 #pragma unroll
         for (int a = 0; a < FN; ++a)
 #pragma unroll
             for (int b = 0; b < FM; ++b) acc[a][b] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};
         for (int kt = 0; kt < nk; ++kt) {
+            LC_STAMP(2)
             __builtin_amdgcn_s_barrier();              // barrier(g)
+            LC_STAMP(0)
             const unsigned char* sb = smem + rslot * SB;
 #pragma unroll
             for (int ss = 0; ss < KSUB; ++ss) {
@@ -244,6 +257,8 @@ __global__ __launch_bounds__((WGM * WGN + NL) * 64) void conv_dma_lc_kernel(cons
             }
         }
     }
+    if (p.clk && lane == 0)
+        for (int i = 0; i < 3; ++i) p.clk[((size_t)blockIdx.x * (NC + NL) + wave) * 3 + i] = clk[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -292,6 +307,25 @@ static hipError_t launch_lc_var(const ConvParams& p, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (e != hipSuccess) return e;
         attr = true;
+    }
+    static const bool clocks = [] { const char* v = std::getenv("YOLOP_LC_CLOCKS"); return v && *v == '1'; }();   // debug: per-phase s_memtime sums
+    if (clocks) {
+        constexpr int NWV = WGM * WGN + NL;
+        ConvParams q = p;
+        const size_t n = (size_t)G * ntiles * NWV * 3;
+        if (hipMalloc((void**)&q.clk, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemset(q.clk, 0, n * 8);
+        hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3(NWV * 64), sh, st, q, mtiles, ntiles, G);
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h(n);
+        (void)hipMemcpy(h.data(), q.clk, n * 8, hipMemcpyDeviceToHost);
+        (void)hipFree(q.clk);
+        const double steps = (double)mtiles / G * (p.Kpad / BK);
+        auto avg = [&](int w, int i) { double s = 0; for (int g = 0; g < G * ntiles; ++g) s += (double)h[((size_t)g * NWV + w) * 3 + i]; return s / (G * ntiles) / steps; };
+        fprintf(stderr, "[lc clocks] %dx%d tile, M=%d K=%d Cout=%d, %d k-steps/tile, %.2f tiles per workgroup; ticks per k-step: consumer 0: barrier wait %.0f, reads+MFMA(+epilogue) %.0f"
+                        " | loader 0: dma wait %.0f, barrier wait %.0f, issue %.0f\n",
+                BM, BN, p.M, p.Kpad, p.Cout, p.Kpad / BK, (double)mtiles / G, avg(0, 0), avg(0, 2), avg(WGM * WGN, 0), avg(WGM * WGN, 1), avg(WGM * WGN, 2));
+        return hipGetLastError();
     }
     hipLaunchKernelGGL(kern, dim3(G * ntiles), dim3((WGM * WGN + NL) * 64), sh, st, p, mtiles, ntiles, G);
     return hipGetLastError();
