@@ -6,6 +6,7 @@
 // kernel exists for them. yp_forward replays the op list on a HIP stream (optionally as one hipGraph).
 #include "../../include/yolop.h"
 #include "common.h"
+#include <algorithm>
 
 #include <cmath>
 #include <cstdarg>
@@ -818,12 +819,14 @@ static int autotune(yp_engine& e) {
         if (!conv_dma_supported(p)) continue;
         float best = 1e30f;
         int bestc = -1;
+        std::vector<std::pair<float, int>> timed;                           // (first-pass time, cfg) of every candidate
         for (int c = 0; c < conv_dma_num_cfgs(); ++c) {
             if (p.x2_C > 0 || !conv_dma_cfg_valid(p, c)) continue;          // (the one-tile-per-workgroup family has no folded-upsample gather)
             o.cfg = c;
             float tmin;
             hipError_t err = time_cfg(o, tmin);
             if (err != hipSuccess) return fail(YP_ERR_HIP, "autotune op %s cfg %d: %s", o.name.c_str(), c, hipGetErrorString(err));
+            timed.emplace_back(tmin, c);
             if (tmin < best) { best = tmin; bestc = c; }
         }
         if (o.kind == OP_CONV) {
@@ -842,7 +845,25 @@ static int autotune(yp_engine& e) {
                 float tmin;
                 hipError_t err = time_cfg(o, tmin);
                 if (err != hipSuccess) return fail(YP_ERR_HIP, "autotune op %s cfg %d: %s", o.name.c_str(), cc, hipGetErrorString(err));
+                timed.emplace_back(tmin, cc);
                 if (tmin < best) { best = tmin; bestc = cc; }
+            }
+        }
+        // second pass over the three fastest: a minimum of three samples is noisy enough that a 5 % slower configuration sometimes
+        // wins the first pass, and one bad pick on a 50-us layer costs the whole step 1-2 %
+        if (timed.size() > 1) {
+            std::sort(timed.begin(), timed.end());
+            best = 1e30f;
+            for (size_t k = 0; k < std::min<size_t>(3, timed.size()); ++k) {
+                o.cfg = timed[k].second;
+                float t = timed[k].first;
+                for (int again = 0; again < 2; ++again) {
+                    float tmin;
+                    hipError_t err = time_cfg(o, tmin);
+                    if (err != hipSuccess) return fail(YP_ERR_HIP, "autotune op %s cfg %d: %s", o.name.c_str(), o.cfg, hipGetErrorString(err));
+                    t = std::min(t, tmin);
+                }
+                if (t < best) { best = t; bestc = timed[k].second; }
             }
         }
         o.cfg = bestc;
