@@ -8,15 +8,20 @@
 One step = one pass of the hot path over one batch of 32 synthetic 640x640 uint8 BGR frames per GPU that are
 already resident in HBM: stem (u8->bf16, /255, BGR->RGB) -> backbone -> neck -> one-to-one head -> DFL decode ->
 two-stage top-k -> [32,300,6]; at N>1 followed by the single RCCL all-gather of the detections. Frames are
-sharded across ranks (weak scaling: 32 frames per GPU). Rank 0 prints ONE JSON line.
+sharded across ranks (weak scaling: 32 frames per GPU). Rank 0 prints the result as ONE JSON line - the LAST line of stdout; when
+the roofline / cpu_baseline legs are on, the bare measurement is printed first (marked "partial") so that a fault in a diagnostic
+leg cannot cost it.
 """
 from __future__ import annotations
 
 import argparse
+import faulthandler
 import json
 import os
 import sys
 import time
+
+faulthandler.enable()       # a native fault prints the interpreter stack (libyolop adds the native backtrace in front of it)
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -129,8 +134,7 @@ def main():
                idx=torch.empty((B, 300), dtype=torch.int32, device=dev),
                coeff=torch.empty((B, 300, 32), dtype=torch.float32, device=dev) if a.seg else None)
     # N>1: two detection buffers so that the all-gather of step i (RCCL stream) overlaps the forward of step i+1
-    # (the engine's hipGraph is keyed on its output pointers, so it keeps ONE output buffer; the 230 KB of detections are
-    # copied to alternating send buffers)
+    # (the 230 KB of detections are copied to alternating send buffers)
     send = [torch.empty_like(out["det"]) for _ in range(2)] if use_dist else None
     gath = [torch.empty((world * B, 300, 6), dtype=torch.float32, device=dev) for _ in range(2)] if use_dist else None
     pending = [None, None]
@@ -173,8 +177,31 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     value = world * B * a.steps / dt
 
+    def line(roof, cpu, partial):
+        d = {
+            "metric": "images/sec", "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+            "config": {"workload": f"YOLOv10-{a.variant.upper()}{'-seg' if a.seg else ''} {S}x{S} bs={B}/GPU {a.dtype}, "
+                                   f"u8 frames resident in HBM -> [B,300,6] detections"
+                                   + (", RCCL all-gather of detections" if world > 1 else ""),
+                       "global_batch": world * B, "imgsz": S, "parallelism": f"frame-shard x{world}",
+                       "weights": "seeded synthetic (SURVEY 8d)", "hipgraph": not a.no_graph},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        if partial:
+            d["partial"] = "measured line; the same line with roofline and cpu_baseline follows"
+        return json.dumps(d)
+
+    want_roof = rank == 0 and not a.no_roofline
+    want_cpu = rank == 0 and world == 1 and not a.no_cpu_baseline
+    if rank == 0 and (want_roof or want_cpu):
+        # the measurement is on stdout before any diagnostic leg runs: a fault in the per-op profile or the CPU baseline cannot cost it.
+        # The LAST line printed is the complete one.
+        print(line(None, None, True), flush=True)
+
     roof = None
-    if rank == 0 and not a.no_roofline:
+    if want_roof:
         try:
             # per-op HIP event pairs on the launch stream (eager replay of the same plan), after the timed region
             eng.set_graph(False)
@@ -214,25 +241,14 @@ def main():
             roof = {"error": f"{type(ex).__name__}: {ex}"}
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if want_cpu:
         try:
             cpu = cpu_baseline(a.variant, a.seg, S, a.cpu_frames)
         except Exception as ex:          # the timed result above stands on its own: report the failure instead of losing the line
             cpu = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0:
-        line = {
-            "metric": "images/sec", "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"YOLOv10-{a.variant.upper()}{'-seg' if a.seg else ''} {S}x{S} bs={B}/GPU {a.dtype}, "
-                                   f"u8 frames resident in HBM -> [B,300,6] detections"
-                                   + (", RCCL all-gather of detections" if world > 1 else ""),
-                       "global_batch": world * B, "imgsz": S, "parallelism": f"frame-shard x{world}",
-                       "weights": "seeded synthetic (SURVEY 8d)", "hipgraph": not a.no_graph},
-            "roofline": roof, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line), flush=True)
+        print(line(roof, cpu, False), flush=True)
     if use_dist:
         if rank == 0 and not (torch.equal(gath[0][:B], out["det"]) and torch.equal(gath[1][:B], out["det"])):
             raise SystemExit("all-gather returned different detections than the local shard")

@@ -142,7 +142,13 @@ int yp_debug_ablation(int v);
    [0] start, [1] keys loaded, [2] stage-1 select done, [3] stage-2 candidates scanned, [4] stage-2 select done, [5] decoded. */
 int yp_debug_head_clocks(uint64_t* out8);
 
-/* Enable/disable hipGraph capture+replay of the forward (default on after the first eager run). */
+/* Host-only self-check of the executor for the current plan (parameter blocks, kernel symbols, tune-cache round trip, lane
+ * schedule invariants). Needs no GPU; returns the number of scheduled launches or <0. Used by the CPU sanitizer build. */
+int yp_debug_host_selftest(yp_engine* e);
+
+/* hipGraph capture + replay of the forward: 0 = eager launches on the caller's stream (the library default), 1 = one hipGraph with
+ * concurrent head lanes replayed on the engine's own stream (what predictor.py, bench.py and smoke() use), 2 = graph without
+ * lanes (A/B). The first forward of every input shape runs once eagerly inside yp_forward before anything is captured. */
 int yp_set_graph(yp_engine* e, int enable);
 
 #ifdef __cplusplus

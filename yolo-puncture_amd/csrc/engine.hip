@@ -7,6 +7,7 @@
 #include "../../include/yolop.h"
 #include "common.h"
 #include <algorithm>
+#include <array>
 
 #include <cmath>
 #include <cstdarg>
@@ -62,8 +63,17 @@ struct yp_engine {
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipGraphExec_t gexec = nullptr;
     std::vector<hipStream_t> lane_streams;   // [0] unused (lane 0 = own_stream)
-    std::vector<hipEvent_t> lane_events;
+    std::vector<hipEvent_t> lane_events;     // [op] "op done" ; [n + lane] join of a side lane ; [n + nl + lane] fork into a side lane
     bool use_lanes = true;
+    // lane schedule of the current plan (pure host data, build_lane_schedule): what run_all_lanes replays
+    struct LaneStep { int op = -1; std::vector<int> waits; bool fork = false; bool record = false; };
+    std::vector<LaneStep> lane_steps;
+    std::vector<int> lanes_used;             // side lanes that launch at least one op under this plan (only these join lane 0)
+    int n_lanes = 1;
+    bool warmed = false;                     // one eager pass of this plan has run (modules loaded, attributes set) - required before a capture
+    // autotuner results per input shape seen so far: switching between shapes re-plans but does not re-tune
+    struct Tuned { int cfg; std::string kernel; };
+    std::map<std::array<int, 3>, std::vector<Tuned>> tuned;
     struct Key { int B = 0, H = 0, W = 0; const void* in = nullptr; } gkey;   // what the captured graph is specialised on
     // engine-owned results of the replayed graph: the graph never references the caller's output buffers (they change from
     // call to call in ordinary use, and every change would mean capture + instantiate + destroy); yp_forward copies the
@@ -112,6 +122,11 @@ struct Builder {
     int weight(const std::string& name, int cout, int cin_g, int k, int groups, bool transposed = false, bool stem = false) {
         WeightDesc w;
         w.name = name; w.cout = cout; w.cin_g = cin_g; w.k = k; w.groups = groups; w.transposed = transposed; w.is_stem = stem;
+        if (!stem && groups == 1) {         // packed GEMM geometry (pack_weight fills exactly this): known from the shape alone, so a plan
+            const int K = transposed ? cin_g : k * k * cin_g;       // made before yp_finalize takes the same decisions as one made after
+            w.Kpad = (K + 31) / 32 * 32;
+            w.mat_bytes = (size_t)((cout + 127) / 128 * 128) * w.Kpad * e.es();
+        }
         e.weights.push_back(w);
         e.wmap[name] = (int)e.weights.size() - 1;
         return (int)e.weights.size() - 1;
@@ -438,7 +453,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
             o.bytes += (double)B * e.desc.max_det * (e.desc.nc + 64 + 6 + 1) * 4;
         }
     }
-    e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false;
+    e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false; e.warmed = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel", "anchor_max_level_kernel"};
     for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; o.fused5 = false; }
@@ -976,32 +991,29 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
         }
 }
 
-static int run_all_lanes(yp_engine& e, const RunArgs& a) {
+// Pure host step: the launch order with its cross-lane waits / records for the current plan. Kept apart from the HIP calls so
+// that (i) it runs once per plan instead of once per capture and (ii) the CPU-only sanitizer build can exercise it.
+static int build_lane_schedule(yp_engine& e) {
     const size_t n = e.ops.size();
     int nl = 1;
     for (const Op& o : e.ops) nl = std::max(nl, o.lane + 1);
-    while ((int)e.lane_streams.size() < nl) {
-        hipStream_t s;
-        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        e.lane_streams.push_back(s);
-    }
-    while (e.lane_events.size() < n + (size_t)nl) {
-        hipEvent_t ev;
-        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        e.lane_events.push_back(ev);
-    }
-    auto stream_of = [&](int lane) { return lane == 0 ? e.own_stream : e.lane_streams[lane]; };
+    e.n_lanes = nl;
+    e.lane_steps.clear();
+    e.lanes_used.clear();
     std::vector<std::vector<View>> rds(n), wrs(n);
     for (size_t i = 0; i < n; ++i) op_views(e, e.ops[i], rds[i], wrs[i]);
-    std::vector<char> recorded(n, 0);
+    std::vector<char> recorded(n, 0), forked(nl, 0);
+    forked[0] = 1;
     for (size_t i = 0; i < n; ++i) {
         const Op& o = e.ops[i];
         if (o.skip) continue;
+        yp_engine::LaneStep stp;
+        stp.op = (int)i;
         // cross-lane dependencies: latest conflicting op of every other lane
         std::vector<int> need(nl, -1);
         for (size_t j = 0; j < i; ++j) {
             const Op& q = e.ops[j];
-            if (q.lane == o.lane) continue;
+            if (q.lane == o.lane || q.skip) continue;
             bool dep = false;
             for (const View& w : wrs[j]) {
                 for (const View& r : rds[i]) dep |= views_overlap(w, r);     // RAW
@@ -1013,17 +1025,24 @@ static int run_all_lanes(yp_engine& e, const RunArgs& a) {
         }
         for (int l = 0; l < nl; ++l) {
             if (need[l] < 0) continue;
-            const int j = need[l];
-            if (!recorded[j]) return fail(YP_ERR_STATE, "internal: dependency %s -> %s was not recorded", e.ops[j].name.c_str(), o.name.c_str());
-            HIPCHK(hipStreamWaitEvent(stream_of(o.lane), e.lane_events[j], 0));
+            if (!recorded[need[l]]) return fail(YP_ERR_STATE, "internal: dependency %s -> %s was not recorded", e.ops[need[l]].name.c_str(), o.name.c_str());
+            stp.waits.push_back(need[l]);
         }
-        hipError_t err = run_op(e, o, a, stream_of(o.lane));
-        if (err != hipSuccess) return fail(YP_ERR_HIP, "launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
-        // record after this op if a later op of another lane conflicts with it, or it is the last op of a side lane
+        // A side lane joins the capture through its first wait on an event of a lane that is already part of it. A first op
+        // without any such dependency (it reads the caller's frames only, say) would otherwise run OUTSIDE the capture: fork it
+        // explicitly from lane 0.
+        if (!forked[o.lane]) {
+            bool via_wait = false;
+            for (int j : stp.waits) via_wait |= forked[e.ops[j].lane] != 0;
+            stp.fork = !via_wait;
+            forked[o.lane] = 1;
+            e.lanes_used.push_back(o.lane);
+        }
+        // record after this op if a later op of another lane conflicts with it
         bool later = false;
         for (size_t k = i + 1; k < n && !later; ++k) {
             const Op& q = e.ops[k];
-            if (q.lane == o.lane) continue;
+            if (q.lane == o.lane || q.skip) continue;
             for (const View& w : wrs[i]) {
                 for (const View& r : rds[k]) later |= views_overlap(w, r);
                 for (const View& w2 : wrs[k]) later |= views_overlap(w, w2);
@@ -1031,13 +1050,50 @@ static int run_all_lanes(yp_engine& e, const RunArgs& a) {
             for (const View& r : rds[i])
                 for (const View& w2 : wrs[k]) later |= views_overlap(r, w2);
         }
-        if (later) {
-            HIPCHK(hipEventRecord(e.lane_events[i], stream_of(o.lane)));
-            recorded[i] = 1;
-        }
+        stp.record = later;
+        if (later) recorded[i] = 1;
+        e.lane_steps.push_back(std::move(stp));
     }
-    // join every side lane back into lane 0 (required to end the capture; harmless otherwise)
-    for (int l = 1; l < nl; ++l) {
+    return YP_OK;
+}
+
+// Streams and events of the lanes. Created ahead of any capture (prepare): nothing is created, loaded or configured while a
+// stream is capturing.
+static int ensure_lane_resources(yp_engine& e) {
+    const size_t n = e.ops.size();
+    while ((int)e.lane_streams.size() < e.n_lanes) {
+        hipStream_t s;
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        e.lane_streams.push_back(s);
+    }
+    while (e.lane_events.size() < n + 2 * (size_t)e.n_lanes) {
+        hipEvent_t ev;
+        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        e.lane_events.push_back(ev);
+    }
+    return YP_OK;
+}
+
+static int run_all_lanes(yp_engine& e, const RunArgs& a) {
+    const size_t n = e.ops.size();
+    const int nl = e.n_lanes;
+    if ((int)e.lane_streams.size() < nl || e.lane_events.size() < n + 2 * (size_t)nl) return fail(YP_ERR_STATE, "internal: lane resources missing");
+    auto stream_of = [&](int lane) { return lane == 0 ? e.own_stream : e.lane_streams[lane]; };
+    for (const yp_engine::LaneStep& stp : e.lane_steps) {
+        const Op& o = e.ops[stp.op];
+        if (stp.fork) {
+            HIPCHK(hipEventRecord(e.lane_events[n + nl + o.lane], e.own_stream));
+            HIPCHK(hipStreamWaitEvent(stream_of(o.lane), e.lane_events[n + nl + o.lane], 0));
+        }
+        for (int j : stp.waits) HIPCHK(hipStreamWaitEvent(stream_of(o.lane), e.lane_events[j], 0));
+        hipError_t err = run_op(e, o, a, stream_of(o.lane));
+        if (err != hipSuccess) return fail(YP_ERR_HIP, "launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
+        if (stp.record) HIPCHK(hipEventRecord(e.lane_events[stp.op], stream_of(o.lane)));
+    }
+    // join the side lanes that took part back into lane 0 (required to end the capture). A lane without ops under this plan
+    // (the mask-coefficient lanes of a detect graph) never forked: touching it here would tie a non-captured event into the
+    // capture, so it is left alone.
+    for (int l : e.lanes_used) {
         HIPCHK(hipEventRecord(e.lane_events[n + l], e.lane_streams[l]));
         HIPCHK(hipStreamWaitEvent(e.own_stream, e.lane_events[n + l], 0));
     }
@@ -1061,9 +1117,11 @@ static void put(std::vector<unsigned char>& buf, size_t idx, float v, int dtype)
     else memcpy(&buf[idx * 4], &v, 4);
 }
 
-static int upload_weight(yp_engine& e, WeightDesc& w) {
+// Host half of the weight hand-over: repack one folded fp32 parameter into the kernel layout (pure host arithmetic, covered by the
+// CPU sanitizer build). main = the packed matrix / tap table, aux = the stem's second (GEMM) layout, else empty.
+static void pack_weight(const yp_engine& e, WeightDesc& w, std::vector<unsigned char>& main, std::vector<unsigned char>& aux) {
     const int es = e.es();
-    std::vector<unsigned char> buf;
+    main.clear(); aux.clear();
     if (w.is_stem) {
         // [ky][kx][c_bgr][co] fp32, values rounded to the engine dtype; BGR memory order <- RGB weight order
         std::vector<float> f((size_t)27 * w.cout);
@@ -1075,37 +1133,33 @@ static int upload_weight(yp_engine& e, WeightDesc& w) {
                         if (e.dtype == DT_BF16) v = bf2f(f2bf(v));
                         f[((size_t)(ky * 3 + kx) * 3 + (2 - ci)) * w.cout + co] = v;
                     }
-        HIPCHK(hipMalloc(&w.d_w, f.size() * 4));
-        HIPCHK(hipMemcpy(w.d_w, f.data(), f.size() * 4, hipMemcpyHostToDevice));
+        main.resize(f.size() * 4);
+        memcpy(main.data(), f.data(), main.size());
         if (e.dtype == DT_BF16) {   // GEMM layout for the MFMA stem: [co][k=(ky,kx,c_bgr)] bf16, K padded 27 -> 32
             std::vector<uint16_t> g((size_t)w.cout * 32, 0);
             for (int co = 0; co < w.cout; ++co)
                 for (int k = 0; k < 27; ++k) g[(size_t)co * 32 + k] = f2bf(f[(size_t)k * w.cout + co]);
-            HIPCHK(hipMalloc(&w.d_w2, g.size() * 2));
-            HIPCHK(hipMemcpy(w.d_w2, g.data(), g.size() * 2, hipMemcpyHostToDevice));
+            aux.resize(g.size() * 2);
+            memcpy(aux.data(), g.data(), aux.size());
         }
     } else if (w.groups > 1) {
         // depthwise: [k*k][C]
         const int C = w.cout, kk = w.k * w.k;
-        buf.assign((size_t)kk * C * es, 0);
+        main.assign((size_t)kk * C * es, 0);
         for (int c = 0; c < C; ++c)
-            for (int t = 0; t < kk; ++t) put(buf, (size_t)t * C + c, w.w[(size_t)c * kk + t], e.dtype);
-        HIPCHK(hipMalloc(&w.d_w, buf.size()));
-        HIPCHK(hipMemcpy(w.d_w, buf.data(), buf.size(), hipMemcpyHostToDevice));
+            for (int t = 0; t < kk; ++t) put(main, (size_t)t * C + c, w.w[(size_t)c * kk + t], e.dtype);
     } else if (w.transposed) {
         // ConvTranspose2d k2 s2: weight [Cin][Cout][2][2] -> 4 GEMM matrices [CoutPad][Kpad], K = Cin
         const int cin = w.cin_g, cout = w.cout;
         w.Kpad = (cin + 31) / 32 * 32;
         const size_t rows = (size_t)(cout + 127) / 128 * 128, sub = rows * w.Kpad;
         w.mat_bytes = sub * es;
-        buf.assign(sub * 4 * es, 0);
+        main.assign(sub * 4 * es, 0);
         for (int dy = 0; dy < 2; ++dy)
             for (int dx = 0; dx < 2; ++dx)
                 for (int co = 0; co < cout; ++co)
                     for (int ci = 0; ci < cin; ++ci)
-                        put(buf, sub * (dy * 2 + dx) + (size_t)co * w.Kpad + ci, w.w[(((size_t)ci * cout + co) * 2 + dy) * 2 + dx], e.dtype);
-        HIPCHK(hipMalloc(&w.d_w, buf.size()));
-        HIPCHK(hipMemcpy(w.d_w, buf.data(), buf.size(), hipMemcpyHostToDevice));
+                        put(main, sub * (dy * 2 + dx) + (size_t)co * w.Kpad + ci, w.w[(((size_t)ci * cout + co) * 2 + dy) * 2 + dx], e.dtype);
     } else {
         // dense: [Cout][Cin][k][k] -> [CoutPad128][Kpad], k order (ky,kx,ci)
         const int cin = w.cin_g, cout = w.cout, k = w.k;
@@ -1113,14 +1167,23 @@ static int upload_weight(yp_engine& e, WeightDesc& w) {
         w.Kpad = (K + 31) / 32 * 32;
         const size_t rows = (size_t)(cout + 127) / 128 * 128;
         w.mat_bytes = rows * w.Kpad * es;
-        buf.assign(rows * w.Kpad * es, 0);
+        main.assign(rows * w.Kpad * es, 0);
         for (int co = 0; co < cout; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int ky = 0; ky < k; ++ky)
                     for (int kx = 0; kx < k; ++kx)
-                        put(buf, (size_t)co * w.Kpad + (size_t)(ky * k + kx) * cin + ci, w.w[(((size_t)co * cin + ci) * k + ky) * k + kx], e.dtype);
-        HIPCHK(hipMalloc(&w.d_w, buf.size()));
-        HIPCHK(hipMemcpy(w.d_w, buf.data(), buf.size(), hipMemcpyHostToDevice));
+                        put(main, (size_t)co * w.Kpad + (size_t)(ky * k + kx) * cin + ci, w.w[(((size_t)co * cin + ci) * k + ky) * k + kx], e.dtype);
+    }
+}
+
+static int upload_weight(yp_engine& e, WeightDesc& w) {
+    std::vector<unsigned char> main, aux;
+    pack_weight(e, w, main, aux);
+    HIPCHK(hipMalloc(&w.d_w, main.size()));
+    HIPCHK(hipMemcpy(w.d_w, main.data(), main.size(), hipMemcpyHostToDevice));
+    if (!aux.empty()) {
+        HIPCHK(hipMalloc(&w.d_w2, aux.size()));
+        HIPCHK(hipMemcpy(w.d_w2, aux.data(), aux.size(), hipMemcpyHostToDevice));
     }
     HIPCHK(hipMalloc((void**)&w.d_b, (size_t)w.cout * 4));
     HIPCHK(hipMemcpy(w.d_b, w.b.data(), (size_t)w.cout * 4, hipMemcpyHostToDevice));
@@ -1143,18 +1206,40 @@ extern "C" {
 
 const char* yp_last_error(void) { return g_err; }
 
-// Debug aid (env YOLOP_SEGV_TRACE=1): print a native backtrace when the process takes a SIGSEGV inside the library
+// Fatal-signal aid, on by default (YOLOP_SEGV_TRACE=0 turns it off): a native backtrace on stderr when the process takes a
+// SIGSEGV / SIGABRT / SIGBUS (glibc's heap checks end in abort()), then the default action. Async-signal-safe calls only.
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
-static void yp_segv_handler(int sig) {
+static struct sigaction g_prev_sa[3];
+static const int g_fatal_sigs[3] = {SIGSEGV, SIGABRT, SIGBUS};
+static void yp_fatal_handler(int sig) {
     void* frames[64];
     const int n = backtrace(frames, 64);
-    const char msg[] = "\n[yolop] SIGSEGV - native backtrace:\n";
-    (void)!write(2, msg, sizeof(msg) - 1);
+    const char* msg = sig == SIGSEGV ? "\n[yolop] SIGSEGV - native backtrace:\n" : sig == SIGABRT ? "\n[yolop] SIGABRT - native backtrace:\n" : "\n[yolop] SIGBUS - native backtrace:\n";
+    (void)!write(2, msg, strlen(msg));
     backtrace_symbols_fd(frames, n, 2);
-    signal(sig, SIG_DFL);
+    // hand over to whoever was installed before us (Python's faulthandler prints the interpreter stack), else the default action
+    for (int i = 0; i < 3; ++i)
+        if (g_fatal_sigs[i] == sig) (void)sigaction(sig, &g_prev_sa[i], nullptr);
     raise(sig);
+}
+static void install_fatal_handlers() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const char* tr = std::getenv("YOLOP_SEGV_TRACE");
+    if (tr && *tr == '0') return;
+    void* warm[2];
+    (void)backtrace(warm, 2);                    // loads libgcc now: the first backtrace() call allocates, which a handler must not
+    for (int i = 0; i < 3; ++i) {
+        struct sigaction sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sa_handler = yp_fatal_handler;
+        sigemptyset(&sa.sa_mask);
+        sa.sa_flags = SA_NODEFER | SA_ONSTACK;
+        if (sigaction(g_fatal_sigs[i], &sa, &g_prev_sa[i]) != 0) g_prev_sa[i].sa_handler = SIG_DFL;
+    }
 }
 
 int yp_create(const yp_model_desc* desc, int device, yp_engine** out) {
@@ -1162,7 +1247,7 @@ int yp_create(const yp_model_desc* desc, int device, yp_engine** out) {
     if (desc->nc <= 0 || desc->max_det <= 0 || desc->max_det > 1024) return fail(YP_ERR_ARG, "bad nc/max_det");
     if (desc->dtype != YP_BF16 && desc->dtype != YP_F32) return fail(YP_ERR_ARG, "bad dtype");
     if (desc->task != YP_TASK_DETECT && desc->task != YP_TASK_SEGMENT) return fail(YP_ERR_ARG, "bad task");
-    { const char* tr = std::getenv("YOLOP_SEGV_TRACE"); if (tr && *tr == '1') signal(SIGSEGV, yp_segv_handler); }
+    install_fatal_handlers();
     std::unique_ptr<yp_engine> e(new yp_engine());
     e->desc = *desc; e->device = device; e->dtype = desc->dtype;
     { const char* nf = std::getenv("YOLOP_NO_FUSE"); e->fuse = !(nf && *nf == '1'); }
@@ -1343,22 +1428,61 @@ int yp_tensor_read(yp_engine* e, int i, float* host_out) {
     return YP_OK;
 }
 
+static void remember_tuning(yp_engine& e) {
+    std::vector<yp_engine::Tuned> v;
+    v.reserve(e.ops.size());
+    for (const Op& o : e.ops) v.push_back({o.cfg, o.kernel});
+    e.tuned[{e.pB, e.pH, e.pW}] = std::move(v);
+}
+static bool recall_tuning(yp_engine& e) {
+    auto it = e.tuned.find({e.pB, e.pH, e.pW});
+    if (it == e.tuned.end() || it->second.size() != e.ops.size()) return false;
+    for (size_t i = 0; i < e.ops.size(); ++i) { e.ops[i].cfg = it->second[i].cfg; e.ops[i].kernel = it->second[i].kernel; }
+    return true;
+}
+
+// Everything a forward needs that is NOT a launch on the caller's stream: plan, arena, tile configurations, lane schedule and
+// resources, and - once per plan - one eager pass on the engine's own stream. That pass is what makes a later capture safe: the
+// first launch of a kernel loads its code object and sets its LDS attribute, and none of that may happen while a stream is
+// capturing (round-1 bench abort: the only caller whose FIRST forward was already in graph mode).
 static int prepare(yp_engine* e, int B, int H, int W, const uint8_t* in, float* det) {
     if (!e || !in || !det) return fail(YP_ERR_ARG, "null argument");
     if (!e->finalized) return fail(YP_ERR_STATE, "yp_finalize has not been called");
     int rc = make_plan(*e, B, H, W);
     if (rc != YP_OK) return rc;
+    if (e->allocated && e->warmed) return YP_OK;
     const bool fresh = !e->allocated;
-    rc = allocate_plan(*e);
-    if (rc != YP_OK) return rc;
-    if (fresh && e->tune && !load_tune_cache(*e)) {
-        HIPCHK(hipDeviceSynchronize());
-        rc = autotune(*e);
-        HIPCHK(hipDeviceSynchronize());
-        if (rc == YP_OK) save_tune_cache(*e);
+    if (fresh) {
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipDeviceSynchronize());          // the arena may move: nothing of the previous plan (or of the caller's input) may be in flight
+        rc = allocate_plan(*e);
+        if (rc != YP_OK) return rc;
+        if (!recall_tuning(*e)) {
+            if (e->tune && !load_tune_cache(*e)) {
+                rc = autotune(*e);
+                HIPCHK(hipDeviceSynchronize());
+                if (rc != YP_OK) return rc;
+                save_tune_cache(*e);
+            }
+            finish_kernel_names(*e);
+            remember_tuning(*e);
+        }
+        rc = build_lane_schedule(*e);
+        if (rc != YP_OK) return rc;
+        rc = ensure_lane_resources(*e);
+        if (rc != YP_OK) return rc;
+        e->warmed = false;
     }
-    finish_kernel_names(*e);
-    return rc;
+    if (!e->warmed) {
+        const bool seg = e->desc.task == YP_TASK_SEGMENT;
+        RunArgs aw{in, e->o_det, e->o_idx, seg ? e->o_coeff : nullptr};
+        HIPCHK(hipDeviceSynchronize());
+        rc = run_all(*e, aw, e->own_stream);
+        if (rc != YP_OK) return rc;
+        HIPCHK(hipStreamSynchronize(e->own_stream));
+        e->warmed = true;
+    }
+    return YP_OK;
 }
 
 int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
@@ -1431,9 +1555,63 @@ int yp_debug_force_conv_cfg(int cfg) {
     return conv_dma_num_cfgs();
 }
 
+// Host-only walk over everything the executor computes for the current plan short of launching: parameter blocks of every op,
+// exact kernel symbols, tune-cache round trip (when YOLOP_TUNE_CACHE is set), per-shape tuning memo, lane schedule. Needs no GPU;
+// it exists so that the CPU sanitizer build (`make asan`, tools/asan_host.cpp) covers the executor's host code.
+int yp_debug_host_selftest(yp_engine* e) {
+    if (!e) return fail(YP_ERR_ARG, "null engine");
+    if (!e->planned) return fail(YP_ERR_STATE, "yp_plan has not been called");
+    size_t acc = 0;
+    if (!e->finalized)
+        for (WeightDesc& w : e->weights) {
+            if (!w.have_w || !w.have_b || w.w.empty()) continue;
+            std::vector<unsigned char> main, aux;
+            pack_weight(*e, w, main, aux);
+            acc += main.size() + aux.size();
+        }
+    for (const Op& o : e->ops) {
+        if (o.skip) continue;
+        if (o.kind == OP_CONV) {
+            if (o.fused) acc += (size_t)dwpw_params(*e, o).Cout;
+            else if (o.fused3) acc += (size_t)front_params(*e, o, nullptr).C2;
+            else if (o.fused4) acc += (size_t)c2f_params(*e, o).Cout;
+            else acc += (size_t)conv_params(*e, o).Cout;
+        } else if (o.kind == OP_DWCONV && o.fused5) acc += (size_t)scd_params(*e, o).C;
+    }
+    finish_kernel_names(*e);
+    save_tune_cache(*e);
+    (void)load_tune_cache(*e);
+    finish_kernel_names(*e);
+    remember_tuning(*e);
+    if (!recall_tuning(*e)) return fail(YP_ERR_STATE, "internal: tuning memo lost");
+    int rc = build_lane_schedule(*e);
+    if (rc != YP_OK) return rc;
+    // the schedule's own invariants: every wait names an op that records, every side lane that launches is joined exactly once
+    std::vector<char> rec(e->ops.size(), 0);
+    std::vector<char> seen(e->n_lanes, 0);
+    seen[0] = 1;
+    for (const auto& stp : e->lane_steps) {
+        const Op& o = e->ops[stp.op];
+        for (int j : stp.waits)
+            if (!rec[j]) return fail(YP_ERR_STATE, "internal: %s waits on %s, which never records", o.name.c_str(), e->ops[j].name.c_str());
+        if (!seen[o.lane]) {
+            bool via = stp.fork;
+            for (int j : stp.waits) via |= seen[e->ops[j].lane] != 0;
+            if (!via) return fail(YP_ERR_STATE, "internal: lane %d would start outside the capture at %s", o.lane, o.name.c_str());
+            seen[o.lane] = 1;
+        }
+        if (stp.record) rec[stp.op] = 1;
+    }
+    int used = 0;
+    for (int l = 1; l < e->n_lanes; ++l) used += seen[l];
+    if (used != (int)e->lanes_used.size()) return fail(YP_ERR_STATE, "internal: %d side lanes launch but %zu are joined", used, e->lanes_used.size());
+    return (int)e->lane_steps.size() + (acc == 0 ? 0 : 0);
+}
+
 int yp_set_autotune(yp_engine* e, int enable) {
     if (!e) return fail(YP_ERR_ARG, "null engine");
     e->tune = enable != 0;
+    e->tuned.clear();                    // (configurations remembered per shape were chosen under the other setting)
     return YP_OK;
 }
 

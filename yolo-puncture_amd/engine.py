@@ -63,6 +63,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_profile.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]
     lib.yp_set_graph.argtypes = [vp, C.c_int]
     lib.yp_set_autotune.argtypes = [vp, C.c_int]
+    lib.yp_debug_host_selftest.argtypes = [vp]
+    lib.yp_debug_host_selftest.restype = C.c_int
     lib.yp_debug_force_conv_cfg.argtypes = [C.c_int]
     lib.yp_debug_ablation.argtypes = [C.c_int]
     lib.yp_debug_head_clocks.argtypes = [C.POINTER(C.c_uint64)]
@@ -87,7 +89,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_letterbox",
+           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_host_selftest", "yp_letterbox",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy"]
 
 
