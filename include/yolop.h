@@ -92,6 +92,16 @@ int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev
              int retina, uint8_t* masks_out, int64_t* id_out, int32_t* kept_out, int suppress_small,
              int min_area, void* stream);
 
+/* `auto_segment` as the reference normally calls it, with min_side > 0 (yolo_seg/yolo_with_deva.py:45-48,118,140): the frame is
+ * shrunk before predict, so the masks come out at (oh,ow) = the shrunk frame and each FLOAT {0,1} mask is resized to the original
+ * frame (rh,rw) with torchvision `F.resize` (:71-72: bilinear, align_corners=False, antialias) before the area test
+ * `mask.sum() < MIN_AREA_THRESHOLD` (:75, on the resized float mask) and the paint `output_mask[mask > 0.5] = id` (:79).
+ * The resize repeats torch's CPU kernel operation by operation (fp32 weights, horizontal pass first, fused multiply-adds), so the
+ * many exact 0.5 ties of e.g. a 2:3 upscale fall on the same side. boxes in (oh,ow) pixels; id_out int64 [rh,rw]; kept_out int32 [n].
+ * With (rh,rw) == (oh,ow) this is yp_masks(retina=1) with id_out. */
+int yp_id_mask_resized(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev, int n, int oh, int ow, int rh,
+                       int rw, int64_t* id_out, int32_t* kept_out, int suppress_small, int min_area, void* stream);
+
 /* LetterBox on the device (the step before the network inside `.predict`; reference call sites yolo_seg/app.py:86-91,
  * [U] ultralytics LetterBox = cv2.resize INTER_LINEAR + cv2.copyMakeBorder(114)). Engine-free, pure function of its
  * arguments; bit-exact with the fixed-point 8-bit bilinear resize the oracle restates.

@@ -103,6 +103,55 @@ def test_auto_segment_matches_reference_semantics(ckpt):
     assert np.allclose([i.score for i in info], [s for _, s, _ in want_info], atol=1e-4)
 
 
+def test_auto_segment_min_side_480(ckpt):
+    """The reference's NORMAL call (yolo_with_deva.py:118,140: min_side = cfg['size'] > 0): a 720x1280 frame is shrunk to 480x853
+    (cv2.resize), predicted, and every float mask is resized back to 720x1280 (torchvision F.resize, antialiased bilinear) before
+    the float-area test and the `> 0.5` paint. Whole HIP path (device resize, letterbox, network, mask tail, second resize, paint)
+    against the oracle pipeline."""
+    from yolo_puncture_amd import YOLO, auto_segment
+    path, _ = ckpt
+    frame = rand_image((1, 720, 1280, 3), seed=7)[0].numpy()
+    model = YOLO(path, dtype="fp32")
+    h, w = frame.shape[:2]
+    scale = 480 / min(h, w)
+    small = po.resize_bilinear_u8_cv2(frame, int(w * scale), int(h * scale))          # :45-48
+    assert small.shape[:2] == (480, 853)
+    det, masks = _oracle_predict(path, small, 0.9, True)
+    assert det.shape[0] >= 1, "the synthetic checkpoint should put at least one detection above the reference's conf=0.9"
+    ids, info = auto_segment({"MIN_AREA_THRESHOLD": 100}, frame, model, min_side=480, suppress_small_mask=True)
+    want_ids, want_info = po.auto_segment_oracle(masks, det[:, 4], det[:, 5], (h, w), True, 100)
+    assert ids.dtype == torch.int64 and tuple(ids.shape) == (h, w) and ids.is_cuda
+    assert (ids.cpu() != want_ids).float().mean().item() < 2e-4      # (mask pixels whose fp32 logit is within 1e-4 of zero may differ)
+    assert [(i.id, i.category_id) for i in info] == [(a, c) for a, _, c in want_info]
+    assert np.allclose([i.score for i in info], [s for _, s, _ in want_info], atol=1e-4)
+
+
+def test_id_mask_resized_bit_level(ckpt):
+    """yp_id_mask_resized on the engine's own masks: the antialiased bilinear resize (torch's CPU arithmetic restated), float-area
+    test and paint must reproduce `auto_segment_oracle` (= torch F.interpolate(antialias=True) + the reference's loop) BIT FOR BIT -
+    up-scaling 2:3 (thousands of exact 0.5 ties), down-scaling, odd ratios, n = 0 / 1 / many, with suppression."""
+    from yolo_puncture_amd.engine import Engine
+    st, im = make_case("n", 80, True, 0, (2, 96, 160))
+    eng = Engine("n", 80, True, "fp32", 0, state=st)
+    eng.forward(im.cuda())
+    torch.cuda.synchronize()
+    g = torch.Generator().manual_seed(0)
+    for b, (oh, ow), (rh, rw) in ((0, (96, 160), (144, 240)), (1, (200, 333), (90, 160)), (1, (90, 161), (271, 97)), (0, (120, 214), (720, 1280)),
+                                  (1, (96, 160), (96, 160))):
+        for n in (0, 1, 9):
+            coeff = torch.randn(n, 32, generator=g)
+            boxes = torch.rand(n, 4, generator=g) * torch.tensor([ow / 2, oh / 2, ow / 2, oh / 2]) + torch.tensor([0, 0, ow / 2, oh / 2])
+            if n:
+                boxes[0] = torch.tensor([0., 0., float(ow), float(oh)])
+            m, _, _ = eng.masks(b, coeff.cuda(), boxes.cuda(), (oh, ow), retina=True)
+            for min_area in (50, 2000):
+                ids, kept = eng.id_mask_resized(b, coeff.cuda(), boxes.cuda(), (oh, ow), (rh, rw), suppress_small=True, min_area=min_area)
+                wi, winfo = po.auto_segment_oracle(m.cpu().float() if n else None, torch.ones(n), torch.zeros(n), (rh, rw), True, min_area)
+                assert torch.equal(ids.cpu(), wi), ((oh, ow), (rh, rw), n, int((ids.cpu() != wi).sum()))
+                assert [k for k in kept.cpu().tolist() if k > 0] == [a for a, _, _ in winfo]
+    eng.close()
+
+
 def test_mask_kernels_bit_level(ckpt):
     """yp_masks alone on the engine's own prototypes: GEMM -> bilinear -> crop -> >0 and the id paint, n = 0, 1, many,
     boxes touching the borders, with and without small-mask suppression."""

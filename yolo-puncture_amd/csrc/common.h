@@ -296,8 +296,11 @@ struct MaskParams {
     int crop_before;                      // 1: process_mask (crop at proto res then upsample), 0: native (upsample then crop)
     uint8_t* masks; int64_t* ids; int32_t* kept; int32_t* area;
     int suppress_small, min_area;
+    int rh, rw;                           // > 0: second, antialiased bilinear resize of the {0,1} masks to (rh,rw) before the area test and
+                                          // the id paint (auto_segment with min_side > 0); ids is then [rh,rw]
 };
 hipError_t launch_masks(const MaskParams& p, int dtype, hipStream_t st);
+size_t masks_workspace_bytes(const MaskParams& p);
 
 // host-side float -> bf16 (round to nearest even), as the device's v_cvt_pk_bf16_f32
 static inline uint16_t f2bf(float f) {

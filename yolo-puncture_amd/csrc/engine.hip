@@ -1665,14 +1665,16 @@ int yp_proto(const yp_engine* e, const void** proto_dev, int* Hp, int* Wp) {
     return YP_OK;
 }
 
-int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev, int n, int oh, int ow, int retina,
-             uint8_t* masks_out, int64_t* id_out, int32_t* kept_out, int suppress_small, int min_area, void* stream) {
+static int masks_common(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev, int n, int oh, int ow, int retina, int rh, int rw,
+                        uint8_t* masks_out, int64_t* id_out, int32_t* kept_out, int suppress_small, int min_area, void* stream) {
     if (!e) return fail(YP_ERR_ARG, "null engine");
     if (e->proto_t < 0) return fail(YP_ERR_STATE, "engine was not created with YP_TASK_SEGMENT");
     if (!e->allocated) return fail(YP_ERR_STATE, "no forward has run yet");
     if (b < 0 || b >= e->pB || n < 0 || oh <= 0 || ow <= 0) return fail(YP_ERR_ARG, "bad mask arguments");
+    if (n > 0 && (!coeff_dev || !boxes_dev)) return fail(YP_ERR_ARG, "null coefficient / box buffer");
     if (!retina && (oh != e->pH || ow != e->pW)) return fail(YP_ERR_ARG, "retina=0 masks are produced at the letterboxed input size %dx%d", e->pH, e->pW);
     if (kept_out && !id_out) return fail(YP_ERR_ARG, "kept_out needs id_out");
+    if (n > 480) return fail(YP_ERR_ARG, "at most 480 masks per call (coefficients are LDS-resident)");
     HIPCHK(hipSetDevice(e->device));
     const TensorDesc& t = e->tensors[e->proto_t];
     MaskParams p{};
@@ -1690,12 +1692,17 @@ int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev
         p.bsx = (float)t.W / (float)e->pW; p.bsy = (float)t.H / (float)e->pH; p.crop_before = 1;
     }
     p.masks = masks_out; p.ids = id_out; p.kept = kept_out; p.suppress_small = suppress_small; p.min_area = min_area;
+    if (rh > 0 && (rh != oh || rw != ow)) {
+        if (rw <= 0 || !id_out) return fail(YP_ERR_ARG, "the second resize needs a target size and id_out");
+        if ((double)oh / rh > 16.0 || (double)ow / rw > 16.0) return fail(YP_ERR_ARG, "second resize shrinks by more than 16x");
+        p.rh = rh; p.rw = rw;
+    }
     {
-        const size_t need = 2 * (size_t)((n + 3) & ~3) * 4 + (size_t)n * p.ch * p.cw * 4 + (masks_out ? 0 : (size_t)n * oh * ow) + 256;
+        const size_t need = masks_workspace_bytes(p);
         if (need > e->mask_ws_bytes) {
             HIPCHK(hipStreamSynchronize((hipStream_t)stream));
             if (e->mask_ws) HIPCHK(hipFree(e->mask_ws));
-            e->mask_ws = nullptr;
+            e->mask_ws = nullptr; e->mask_ws_bytes = 0;
             HIPCHK(hipMalloc(&e->mask_ws, need));
             e->mask_ws_bytes = need;
         }
@@ -1704,6 +1711,17 @@ int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev
     hipError_t err = launch_masks(p, e->dtype, (hipStream_t)stream);
     if (err != hipSuccess) return fail(YP_ERR_HIP, "mask kernels: %s", hipGetErrorString(err));
     return YP_OK;
+}
+
+int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev, int n, int oh, int ow, int retina,
+             uint8_t* masks_out, int64_t* id_out, int32_t* kept_out, int suppress_small, int min_area, void* stream) {
+    return masks_common(e, b, coeff_dev, boxes_dev, n, oh, ow, retina, 0, 0, masks_out, id_out, kept_out, suppress_small, min_area, stream);
+}
+
+int yp_id_mask_resized(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev, int n, int oh, int ow, int rh, int rw,
+                       int64_t* id_out, int32_t* kept_out, int suppress_small, int min_area, void* stream) {
+    if (rh <= 0 || rw <= 0) return fail(YP_ERR_ARG, "bad target size");
+    return masks_common(e, b, coeff_dev, boxes_dev, n, oh, ow, 1, rh, rw, nullptr, id_out, kept_out, suppress_small, min_area, stream);
 }
 
 }  // extern "C"

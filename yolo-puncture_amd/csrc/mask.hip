@@ -145,10 +145,107 @@ __global__ __launch_bounds__(256) void mask_paint_kernel(const MaskParams p, con
     ids[pix] = id;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Second resize of `auto_segment` when the frame was shrunk before predict (min_side > 0, yolo_seg/yolo_with_deva.py:45-48):
+// every float {0,1} mask at (oh,ow) is resized to the original frame (rh,rw) by torchvision `F.resize` (:71-72) = bilinear,
+// align_corners=False, ANTIALIAS on: a separable triangle filter, horizontal pass first, weights in fp32. The arithmetic below is
+// torch's CPU kernel restated operation by operation (ATen UpSampleKernel: _compute_indices_min_size_weights_aa + the two basic
+// loops), including the places where C++ promotes to double and the fused multiply-adds of the accumulation, because the decision
+// `mask > 0.5` (:79) meets exact ties (a 2:3 upscale puts thousands of pixels at exactly 0.5): bit-equal floats or different ids.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int AA_KMAX = 36;
+__global__ void aa_weights_kernel(int n_in, int n_out, int* xmin, int* xsize, float* W) {
+#pragma clang fp contract(off)
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    const float scale = (float)n_in / (float)n_out;
+    const float support = scale >= 1.f ? scale : 1.f;
+    const float invscale = scale >= 1.f ? 1.f / scale : 1.f;
+    const int K = (int)ceilf(support) * 2 + 1;
+    const float center = (float)((double)scale * ((double)i + 0.5));
+    int lo = (int)((double)(center - support) + 0.5);
+    lo = max(lo, 0);
+    int hi = (int)((double)(center + support) + 0.5);
+    hi = min(hi, n_in);
+    const int sz = min(max(hi - lo, 0), min(K, AA_KMAX));
+    float tot = 0.f;
+    float* w = W + (size_t)i * AA_KMAX;
+    for (int j = 0; j < sz; ++j) {
+        float x = (float)(((double)((float)(j + lo) - center) + 0.5) * (double)invscale);
+        x = fabsf(x);
+        const float v = x < 1.f ? 1.f - x : 0.f;
+        w[j] = v;
+        tot = tot + v;
+    }
+    if (tot != 0.f)
+        for (int j = 0; j < sz; ++j) w[j] = w[j] / tot;
+    xmin[i] = lo;
+    xsize[i] = sz;
+}
+
+// horizontal pass: T[i][y][x] = sum_j w[x][j] * m[i][y][xmin[x]+j]   (m in {0,1}: every product is exact)
+__global__ __launch_bounds__(256) void aa_h_kernel(const uint8_t* masks, int oh, int ow, int rw, const int* xmin, const int* xsize, const float* W, float* T) {
+    const int i = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= oh * rw) return;
+    const int y = pix / rw, x = pix - y * rw;
+    const uint8_t* row = masks + ((size_t)i * oh + y) * ow + xmin[x];
+    const float* w = W + (size_t)x * AA_KMAX;
+    const int sz = xsize[x];
+    float t = sz > 0 ? (float)row[0] * w[0] : 0.f;
+    for (int j = 1; j < sz; ++j) t = fmaf((float)row[j], w[j], t);
+    T[(size_t)i * oh * rw + pix] = t;
+}
+
+// vertical pass + threshold + area: v = sum_j w[y][j] * T[i][ymin[y]+j][x] (first term a product, the rest fused multiply-adds)
+__global__ __launch_bounds__(256) void aa_v_kernel(const float* T, int oh, int rh, int rw, const int* ymin, const int* ysize, const float* W,
+                                                   uint8_t* out, double* area) {
+    const int i = blockIdx.y;
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    float v = 0.f;
+    if (pix < rh * rw) {
+        const int y = pix / rw, x = pix - y * rw;
+        const float* col = T + ((size_t)i * oh + ymin[y]) * rw + x;
+        const float* w = W + (size_t)y * AA_KMAX;
+        const int sz = ysize[y];
+        v = sz > 0 ? __fmul_rn(col[0], w[0]) : 0.f;
+        for (int j = 1; j < sz; ++j) v = fmaf(col[(size_t)j * rw], w[j], v);
+        out[(size_t)i * rh * rw + pix] = v > 0.5f ? 1 : 0;
+    }
+    // mask.sum() of the resized FLOAT mask (yolo_with_deva.py:75), accumulated in double
+    double s = (double)v;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0 && s != 0.0) atomicAdd(&area[i], s);
+}
+
+__global__ void mask_ids_f_kernel(const MaskParams p, const double* area, int32_t* kept) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int cur = 1;
+    for (int i = 0; i < p.n; ++i) {
+        if (p.suppress_small && (float)area[i] < (float)p.min_area) kept[i] = 0;
+        else kept[i] = cur++;
+    }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// bytes of device workspace launch_masks needs for these parameters
+size_t masks_workspace_bytes(const MaskParams& p) {
+    size_t need = 2 * (size_t)((p.n + 3) & ~3) * 4 + (size_t)p.n * p.ch * p.cw * 4 + (p.masks ? 0 : (size_t)p.n * p.oh * p.ow) + 512;
+    if (p.rh > 0)
+        need += align256((size_t)p.n * 8) + 2 * align256((size_t)(p.rw + p.rh) * 4) + align256((size_t)(p.rw + p.rh) * AA_KMAX * 4) +
+                align256((size_t)p.n * p.oh * p.rw * 4) + align256((size_t)p.n * p.rh * p.rw) + 256;
+    return need;
+}
+
 // workspace layout (device, provided by the engine through p.area):  int32 area[n] | int32 kept[n] | float M[n*ch*cw] | u8 masks[n*oh*ow]
+//   (+ when a second resize is asked for: double area_f[n] | int xmin/xsize/ymin/ysize | float Wx/Wy | float T[n*oh*rw] | u8 masks2[n*rh*rw])
 hipError_t launch_masks(const MaskParams& p, int dtype, hipStream_t st) {
+    const bool second = p.rh > 0;
+    const int ph = second ? p.rh : p.oh, pw = second ? p.rw : p.ow;          // size of the painted id image
     if (p.n == 0) {
-        if (p.ids) return hipMemsetAsync(p.ids, 0, (size_t)p.oh * p.ow * sizeof(int64_t), st);
+        if (p.ids) return hipMemsetAsync(p.ids, 0, (size_t)ph * pw * sizeof(int64_t), st);
         return hipSuccess;
     }
     if ((size_t)((p.n + 15) & ~15) * 32 * sizeof(float) > 60 * 1024) return hipErrorInvalidValue;
@@ -170,11 +267,31 @@ hipError_t launch_masks(const MaskParams& p, int dtype, hipStream_t st) {
         else hipLaunchKernelGGL(mask_gemm_mfma_kernel<float>, dim3((npix + 63) / 64), dim3(256), sh, st, p, M);
     }
     hipLaunchKernelGGL(mask_resize_kernel, dim3((p.oh * p.ow + 255) / 256, p.n), dim3(256), 0, st, p, M, masks, area);
-    if (p.ids) {
-        int32_t* kept = p.kept ? p.kept : kept_ws;
+    if (!p.ids) return hipGetLastError();
+    int32_t* kept = p.kept ? p.kept : kept_ws;
+    if (!second) {
         hipLaunchKernelGGL(mask_ids_kernel, dim3(1), dim3(64), 0, st, p, area, kept);
         hipLaunchKernelGGL(mask_paint_kernel, dim3((p.oh * p.ow + 255) / 256), dim3(256), 0, st, p, masks, kept, p.ids);
+        return hipGetLastError();
     }
+    if ((float)p.oh / (float)p.rh > 16.f || (float)p.ow / (float)p.rw > 16.f) return hipErrorInvalidValue;   // (AA_KMAX taps)
+    char* q = (char*)(p.masks ? (uint8_t*)(M + (size_t)p.n * p.ch * p.cw) : masks + (size_t)p.n * p.oh * p.ow);
+    q = (char*)(((uintptr_t)q + 255) & ~(uintptr_t)255);
+    double* area_f = (double*)q; q += align256((size_t)p.n * 8);
+    int* xmin = (int*)q; int* xsize = xmin + p.rw; int* ymin = xsize + p.rw; int* ysize = ymin + p.rh; q += 2 * align256((size_t)(p.rw + p.rh) * 4);
+    float* Wx = (float*)q; float* Wy = Wx + (size_t)p.rw * AA_KMAX; q += align256((size_t)(p.rw + p.rh) * AA_KMAX * 4);
+    float* T = (float*)q; q += align256((size_t)p.n * p.oh * p.rw * 4);
+    uint8_t* masks2 = (uint8_t*)q;
+    e = hipMemsetAsync(area_f, 0, (size_t)p.n * sizeof(double), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(aa_weights_kernel, dim3((p.rw + 63) / 64), dim3(64), 0, st, p.ow, p.rw, xmin, xsize, Wx);
+    hipLaunchKernelGGL(aa_weights_kernel, dim3((p.rh + 63) / 64), dim3(64), 0, st, p.oh, p.rh, ymin, ysize, Wy);
+    hipLaunchKernelGGL(aa_h_kernel, dim3((p.oh * p.rw + 255) / 256, p.n), dim3(256), 0, st, masks, p.oh, p.ow, p.rw, xmin, xsize, Wx, T);
+    hipLaunchKernelGGL(aa_v_kernel, dim3((p.rh * p.rw + 255) / 256, p.n), dim3(256), 0, st, T, p.oh, p.rh, p.rw, ymin, ysize, Wy, masks2, area_f);
+    hipLaunchKernelGGL(mask_ids_f_kernel, dim3(1), dim3(64), 0, st, p, area_f, kept);
+    MaskParams pp = p;
+    pp.oh = p.rh; pp.ow = p.rw;
+    hipLaunchKernelGGL(mask_paint_kernel, dim3((p.rh * p.rw + 255) / 256), dim3(256), 0, st, pp, masks2, kept, p.ids);
     return hipGetLastError();
 }
 

@@ -9,7 +9,6 @@ from typing import Dict, List, NamedTuple, Tuple
 import numpy as np
 import torch
 
-from . import hostops
 
 
 class ObjectInfo(NamedTuple):
@@ -25,12 +24,13 @@ def auto_segment(config: Dict, image: np.ndarray, yolo_model, min_side: int, sup
     reference does with its RGB frames - SURVEY Appendix C-6); returns (int64 [h,w] on the model's device, [ObjectInfo])."""
     device = next(yolo_model.model.parameters()).device                     # :42
     h, w = image.shape[:2]
-    if min_side > 0:                                                        # :45-48 (cv2.resize default = INTER_LINEAR)
+    pre = None
+    if min_side > 0:                                                        # :45-48 (cv2.resize default = INTER_LINEAR), done on the GPU
         scale = min_side / min(h, w)
-        image = hostops.resize_linear_u8(np.ascontiguousarray(image), int(w * scale), int(h * scale))
+        pre = (int(w * scale), int(h * scale))
     min_area = config.get("MIN_AREA_THRESHOLD", 100) if hasattr(config, "get") else 100
     ids, kept, conf, cls = yolo_model.predict_id_mask(image, conf=0.9, out_hw=(h, w), suppress_small=suppress_small_mask,
-                                                      min_area=int(min_area))   # :51-79 fused
+                                                      min_area=int(min_area), pre_resize=pre)   # :45-79 fused
     segments_info = []
     kept = kept.tolist()
     for i, k in enumerate(kept):                                            # :82-86 ids consecutive over KEPT masks

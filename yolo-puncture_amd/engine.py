@@ -51,6 +51,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_forward.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
     lib.yp_proto.argtypes = [vp, C.POINTER(vp), ip, ip]
     lib.yp_masks.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.yp_id_mask_resized.argtypes = [vp, C.c_int, vp, vp] + [C.c_int] * 5 + [vp, vp, C.c_int, C.c_int, vp]
+    lib.yp_id_mask_resized.restype = C.c_int
     lib.yp_plan.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.yp_op_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.yp_op_output.argtypes = [vp, C.c_int, ip, ip, ip]
@@ -87,7 +89,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
-           "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output",
+           "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
            "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_host_selftest", "yp_letterbox",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy"]
@@ -229,6 +231,23 @@ class Engine:
                                     1 if suppress_small else 0, int(min_area), C.c_void_p(_stream_ptr(dev))))
         self._keep = [coeff, boxes]
         return m, ids, kept
+
+    def id_mask_resized(self, b: int, coeff: torch.Tensor, boxes: torch.Tensor, mask_hw: Tuple[int, int], out_hw: Tuple[int, int],
+                        suppress_small: bool = False, min_area: int = 100):
+        """`auto_segment` with min_side > 0 (yp_id_mask_resized): masks at `mask_hw` (the shrunk frame), antialiased bilinear to
+        `out_hw`, float-area test, paint. -> (ids int64 [out_hw] cuda, kept int32 [n] cuda)"""
+        n = int(coeff.shape[0])
+        dev = coeff.device
+        coeff = coeff.to(torch.float32).contiguous()
+        boxes = boxes.to(torch.float32).contiguous()
+        ids = torch.empty((int(out_hw[0]), int(out_hw[1])), dtype=torch.int64, device=dev)
+        kept = torch.empty((n,), dtype=torch.int32, device=dev)
+        self._chk(self.lib.yp_id_mask_resized(self._h, b, C.c_void_p(coeff.data_ptr()), C.c_void_p(boxes.data_ptr()), n, int(mask_hw[0]),
+                                              int(mask_hw[1]), int(out_hw[0]), int(out_hw[1]), C.c_void_p(ids.data_ptr()),
+                                              C.c_void_p(kept.data_ptr()), 1 if suppress_small else 0, int(min_area),
+                                              C.c_void_p(_stream_ptr(dev))))
+        self._keep = [coeff, boxes]
+        return ids, kept
 
     # -- introspection ---------------------------------------------------------------------------------------------
     def plan(self, B: int, H: int, W: int) -> List[dict]:

@@ -26,6 +26,22 @@ from .weights import read_ultralytics_pt, synthetic_state
 _ENGINE_CACHE: Dict[tuple, Engine] = {}
 
 
+def shutdown() -> None:
+    """Destroy every cached engine now (device memory, streams, graphs). Registered with atexit so that it runs while the HIP
+    runtime and torch are still alive - not from `Engine.__del__` during interpreter teardown."""
+    while _ENGINE_CACHE:
+        _, eng = _ENGINE_CACHE.popitem()
+        try:
+            eng.close()
+        except Exception:
+            pass
+
+
+import atexit  # noqa: E402
+
+atexit.register(shutdown)
+
+
 class Boxes:
     """[n,6] rows = x1,y1,x2,y2 (original-image pixels), conf, cls; sorted by conf descending."""
 
@@ -225,6 +241,10 @@ class YOLO:
         eng = _ENGINE_CACHE.get(key)
         if eng is None:
             eng = Engine(self.variant, self.nc, self.seg, self.dtype, self._dev_index, state=self._state)
+            # the reference's real workload is one frame per call (yolo_seg/app.py:85-91): ~90 eager launches per frame would be
+            # launch-bound, so the forward is replayed as one hipGraph per input shape (the engine runs every new shape once eagerly
+            # before it captures; the graph is keyed on the input pointer, hence the persistent batch buffers below)
+            eng.set_graph(os.environ.get("YOLOP_PREDICT_GRAPH", "1") != "0")
             _ENGINE_CACHE[key] = eng
         return eng
 
@@ -261,8 +281,7 @@ class YOLO:
             for bi, i in enumerate(idxs):
                 raw = torch.from_numpy(np.ascontiguousarray(imgs[i])).to(dev, non_blocking=True)
                 letterbox_device(raw, geos[i], out=batch[bi])
-            # one output set per batch size: new buffers on every call would re-capture the engine's hipGraph each time (it is
-            # keyed on its output pointers); everything handed to the caller below is copied out of these buffers
+            # one output set per batch size (no allocation per call); everything handed to the caller below is copied out of it
             cache = self.__dict__.setdefault("_out_cache", {})
             okey = (self._dev_index, len(idxs))
             out = eng.forward(batch, cache.get(okey))
@@ -291,25 +310,31 @@ class YOLO:
         return results
 
     def predict_id_mask(self, image: np.ndarray, conf: float = 0.9, out_hw: Optional[Tuple[int, int]] = None,
-                        suppress_small: bool = False, min_area: int = 100, imgsz: int = 640):
-        """The fused tail of `auto_segment` (reference yolo_seg/yolo_with_deva.py:51-86): predict(retina_masks=True,
-        conf) -> masks at the frame's size -> (bilinear to `out_hw` if it differs, :71-72) -> area test -> id paint.
+                        suppress_small: bool = False, min_area: int = 100, imgsz: int = 640,
+                        pre_resize: Optional[Tuple[int, int]] = None):
+        """The fused body of `auto_segment` (reference yolo_seg/yolo_with_deva.py:45-86): (cv2.resize to `pre_resize` = (w,h), :45-48)
+        -> predict(retina_masks=True, conf) -> masks at the fed frame's size -> (antialiased bilinear to `out_hw` if it differs,
+        :71-72) -> area test -> id paint, all on the GPU: the raw frame is uploaded once.
         -> (ids int64 [h,w] cuda, kept int32 [n] cpu (id per detection, 0 = suppressed), conf [n] cpu, cls [n] cpu)"""
         if not self.seg:
             raise ValueError("auto_segment needs a segmentation checkpoint")
         imgs, _ = hostops.load_sources(image)
         im = imgs[0]
-        oh, ow = im.shape[:2]
-        out_hw = (oh, ow) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
         eng = self._engine()
         dev = torch.device("cuda", self._dev_index)
+        raw = torch.from_numpy(np.ascontiguousarray(im)).to(dev)
+        if pre_resize is not None and (int(pre_resize[1]), int(pre_resize[0])) != tuple(im.shape[:2]):
+            nw, nh = int(pre_resize[0]), int(pre_resize[1])
+            raw = letterbox_device(raw, dict(out_h=nh, out_w=nw, new_h=nh, new_w=nw, top=0, left=0))   # cv2.resize(INTER_LINEAR) on the device
+        oh, ow = int(raw.shape[0]), int(raw.shape[1])
+        out_hw = (oh, ow) if out_hw is None else (int(out_hw[0]), int(out_hw[1]))
         geo = hostops.letterbox_geometry(oh, ow, imgsz)
         H, W = geo["out_h"], geo["out_w"]
         bcache = self.__dict__.setdefault("_batch_cache", {})
         batch = bcache.get((self._dev_index, 1, H, W))
         if batch is None:
             batch = bcache[(self._dev_index, 1, H, W)] = torch.empty((1, H, W, 3), dtype=torch.uint8, device=dev)
-        letterbox_device(torch.from_numpy(np.ascontiguousarray(im)).to(dev), geo, out=batch[0])
+        letterbox_device(raw, geo, out=batch[0])
         out = eng.forward(batch)
         d = out["det"][0]
         keep = d[:, 4] > conf
@@ -325,17 +350,7 @@ class YOLO:
             _, ids, kept = eng.masks(0, cf, boxes, (oh, ow), retina=True, want_masks=False, want_ids=True,
                                      suppress_small=suppress_small, min_area=min_area)
         else:
-            # the reference resizes each float mask to (h,w) and thresholds at 0.5 (:71-79); do the same on the GPU tensors
-            m, _, _ = eng.masks(0, cf, boxes, (oh, ow), retina=True)
-            mf = torch.nn.functional.interpolate(m[None].float(), size=out_hw, mode="bilinear", align_corners=False,
-                                                 antialias=True)[0]
-            ids = torch.zeros(out_hw, dtype=torch.int64, device=dev)
-            kept = torch.zeros(n, dtype=torch.int32)
-            cur = 1
-            for i in range(n):
-                if suppress_small and float(mf[i].sum()) < min_area:
-                    continue
-                ids[mf[i] > 0.5] = cur
-                kept[i] = cur
-                cur += 1
+            # the reference resizes each float mask to (h,w) (torchvision F.resize: antialiased bilinear), tests the float area and
+            # thresholds at 0.5 (:71-79): one GPU pass (yp_id_mask_resized)
+            ids, kept = eng.id_mask_resized(0, cf, boxes, (oh, ow), out_hw, suppress_small=suppress_small, min_area=min_area)
         return ids, kept.cpu(), d[:, 4].cpu(), d[:, 5].cpu()
