@@ -9,7 +9,7 @@ from yolo_puncture_amd.weights import synthetic_state
 ap = argparse.ArgumentParser()
 ap.add_argument("--ops", default="model.8.cv1,model.2.cv2,model.16.cv1,model.6.m.0.cv2,model.1,model.4.m.0.cv1")
 ap.add_argument("--batch", type=int, default=32); ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--out", default="")
+ap.add_argument("--out", default=""); ap.add_argument("--cfgs", default="")
 a = ap.parse_args()
 lib = load_library()
 eng = Engine("s", 80, False, "bf16", 0, state=synthetic_state("s", 80, False))
@@ -18,7 +18,8 @@ im = torch.randint(0, 256, (a.batch, 640, 640, 3), dtype=torch.uint8).cuda()
 out = eng.forward(im); torch.cuda.synchronize()
 ops = eng.plan(a.batch, 640, 640)
 lines = []
-cfgs = list(range(14)) + [100, 101, 102, 103] + [200, 201, 202, 203, 204] + list(range(300, 341)) + list(range(400, 409)) + list(range(500, 505)) + [600, 601]
+cfgs = list(range(14)) + [100, 101, 102, 103] + [200, 201, 202, 203, 204] + list(range(300, 341)) + list(range(400, 409)) + list(range(500, 505)) + [600, 601] + list(range(700, 713))
+if a.cfgs: cfgs = [int(x) for x in a.cfgs.split(',')]
 for name in a.ops.split(","):
     idx = [i for i, o in enumerate(ops) if o["name"] == name][0]
     o = ops[idx]

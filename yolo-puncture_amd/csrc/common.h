@@ -242,6 +242,11 @@ int conv_tile1_num_cfgs();
 bool conv_tile1_cfg_valid(const ConvParams& p, int c);
 const char* conv_tile1_kernel_name(int c);
 hipError_t launch_conv_tile1(const ConvParams& p, int c, hipStream_t st);
+// weights-in-registers 3x3 s1 kernel (conv_wreg.hip); ids offset by 700
+int conv_wreg_num_cfgs();
+bool conv_wreg_cfg_valid(const ConvParams& p, int c);
+const char* conv_wreg_kernel_name(int c);
+hipError_t launch_conv_wreg(const ConvParams& p, int c, hipStream_t st);
 int conv_halo_s2_num_cfgs();
 bool conv_halo_s2_cfg_valid(const ConvParams& p, int c);
 const char* conv_halo_s2_kernel_name(int c);

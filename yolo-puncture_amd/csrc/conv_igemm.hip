@@ -253,6 +253,7 @@ static int halo_choice(const ConvParams& p, int dtype) {
         return -2;
     }
     auto valid = [&](int c) {
+        if (c >= 700) return conv_wreg_cfg_valid(p, c - 700);
         if (c >= 600) return conv_tile1_cfg_valid(p, c - 600);
         if (c >= 500) return conv_halo_s2_cfg_valid(p, c - 500);
         if (c >= 400) return conv_dma_lc_cfg_valid(p, c - 400);
@@ -270,6 +271,7 @@ static int halo_choice(const ConvParams& p, int dtype) {
 
 const char* conv_kernel_name(const ConvParams& p, int dtype) {
     const int h = halo_choice(p, dtype);
+    if (h >= 700) return conv_wreg_kernel_name(h - 700);
     if (h >= 600) return conv_tile1_kernel_name(h - 600);
     if (h >= 500) return conv_halo_s2_kernel_name(h - 500);
     if (h >= 400) return conv_dma_lc_kernel_name(h - 400);
@@ -305,6 +307,7 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t st) {
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st) {
     const int h = halo_choice(p, dtype);
     if (p.x2_C > 0 && h < 300) return hipErrorInvalidValue;      // (the plan folds an upsample only when such a configuration exists)
+    if (h >= 700) return launch_conv_wreg(p, h - 700, st);
     if (h >= 600) return launch_conv_tile1(p, h - 600, st);
     if (h >= 500) return launch_conv_halo_s2(p, h - 500, st);
     if (h >= 400) return launch_conv_dma_lc(p, h - 400, st);
