@@ -111,6 +111,28 @@ int yp_id_mask_resized(yp_engine* e, int b, const float* coeff_dev, const float*
 int yp_letterbox(const uint8_t* src_dev, int h0, int w0, uint8_t* dst_dev, int out_h, int out_w, int new_h, int new_w,
                  int top, int left, int pad_value, void* stream);
 
+/* -- U^2-Net-P / U^2-Net: the second per-frame network of the reference's video loop, `unet_predict(unet_model,
+ *    cropped_frame)` at yolo_seg/app.py:184. Model: yolo_seg/tasks/models/U2Net.py:424-526 (U2NETP) / :318-420 (U2NET); loader and
+ *    post-process: yolo_seg/tasks/unet_segment.py:32-73. variant 'p' = U2NETP, 'f' = U2NET. Weights are handed over folded (conv +
+ *    eval-mode BatchNorm -> one weight/bias pair per REBNCONV, named like the reference modules: "stage1.rebnconvin.weight", ...,
+ *    "side1.weight", "outconv.weight"), exactly like yp_set_weight.
+ *    yp_u2net_forward: bgr_dev uint8 [B,H,W,3] BGR (what cv2 hands the reference; BGR->RGB and /255 of numpy2tensor happen on the device),
+ *      prob_out float [B,H,W] = sigmoid(d0), the first of the model's seven outputs (required)
+ *      norm_out float [B,H,W] = normPRED(prob) = (p - min) / (max - min) over the whole call (may be NULL)
+ *      mask_out uint8 [B,H,W] = norm > 0.5 ? 255 : 0, the array `unet_predict` returns (may be NULL) */
+typedef struct yp_u2net yp_u2net;
+int yp_u2net_create(int variant, int dtype, int device, yp_u2net** out);
+int yp_u2net_destroy(yp_u2net* e);
+int yp_u2net_weight_count(const yp_u2net* e);
+int yp_u2net_weight_info(const yp_u2net* e, int i, char* name, int name_cap, int64_t shape[4], int* ndim);
+int yp_u2net_set_weight(yp_u2net* e, const char* name, const float* host, const int64_t* shape, int ndim);
+int yp_u2net_finalize(yp_u2net* e);
+int yp_u2net_forward(yp_u2net* e, const uint8_t* bgr_dev, int B, int H, int W, float* prob_out, float* norm_out,
+                     uint8_t* mask_out, void* stream);
+int yp_u2net_tensor_count(const yp_u2net* e);
+int yp_u2net_tensor_info(const yp_u2net* e, int i, char* name, int name_cap, int dims[4] /*B,H,W,C*/);
+int yp_u2net_tensor_read(yp_u2net* e, int i, float* host_out);   /* sync copy NHWC -> fp32 host (debug taps) */
+
 /* -- multi-GPU: frames are sharded over one process per GPU; the only data-path collective is ONE all-gather of
  *    the [B/G,max_det,6] detections per batch over RCCL (xGMI). The reference has no multi-GPU path (frames are independent inside
  *    `.predict`, yolo_seg/app.py:85-91). bench.py / parallel.py use torch.distributed's "nccl" backend for it; these entry points

@@ -66,3 +66,30 @@ def test_errors_are_loud():
             e.finalize()                              # no GPU here -> no silent CPU fallback
         assert lib.yp_forward(e._h, None, 1, 64, 64, None, None, None, None) < 0
     e.close()
+
+
+def test_u2net_weight_table_equals_reference_module():
+    """yp_u2net_create's own graph (C++ builder) names and shapes every parameter exactly as the REFERENCE nn.Module does
+    (tests/golden/u2netp_params.npz was written from the reference's state_dict), after the conv+BatchNorm fold."""
+    import numpy as np
+    from yolo_puncture_amd.u2net import U2NetEngine, fold_state, synthetic_state
+    z = np.load(os.path.join(ROOT, "tests", "golden", "u2netp_params.npz"))
+    ref = {str(k): tuple(int(x) for x in str(s).split(",")) if str(s) else () for k, s in zip(z["names"], z["shapes"])}
+    e = U2NetEngine("p", "fp32", 0)
+    exp = dict(e.expected_weights())
+    folded = {}
+    for k, (w, b) in fold_state(synthetic_state("p", 0), "p").items():
+        folded[k + ".weight"], folded[k + ".bias"] = tuple(w.shape), tuple(b.shape)
+    assert exp == folded
+    for k, shp in exp.items():                      # every engine parameter is a conv of the reference with that shape
+        base, kind = k.rsplit(".", 1)
+        rk = f"{base}.conv_s1.{kind}" if f"{base}.conv_s1.{kind}" in ref else k
+        assert ref[rk] == shp, (k, rk)
+    assert sum(1 for k in ref if k.endswith("conv_s1.weight") or k in ("outconv.weight",) or (k.startswith("side") and k.endswith(".weight"))) * 2 == len(exp)
+    e.load_state(synthetic_state("p", 0))
+    if not torch.cuda.is_available():
+        with pytest.raises(YolopError, match="no HIP device"):
+            e.finalize()
+    e.close()
+    with pytest.raises(YolopError, match="variant"):
+        U2NetEngine("q", "fp32", 0)

@@ -14,6 +14,9 @@ def __getattr__(name):
     if name in ("Engine", "load_library"):
         from . import engine
         return getattr(engine, name)
+    if name in ("load_unet", "unet_predict", "U2NetEngine"):
+        from . import u2net
+        return getattr(u2net, name)
     if name == "auto_segment":
         from .deva_adapter import auto_segment
         return auto_segment

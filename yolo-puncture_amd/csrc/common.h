@@ -8,7 +8,7 @@
 namespace yp {
 
 enum DType { DT_BF16 = 0, DT_F32 = 1 };
-enum Act { ACT_NONE = 0, ACT_SILU = 1 };
+enum Act { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2 };   // (ReLU: conv_igemm only - the U^2-Net path)
 
 enum OpKind {
     OP_STEM = 0,      // u8 BGR NHWC -> first 3x3 s2 conv (+/255, BGR->RGB fused)
@@ -110,6 +110,7 @@ struct ConvParams {
     // y / y_stride / y_coff / y_bytes describe the FINAL output of C2 channels
     const void* w2; const float* bias2; int C2, act2, Kpad2; size_t w2_bytes;
     unsigned long long* clk;                    // debug (YOLOP_LC_CLOCKS=1, conv_dma_lc only): per-wave phase clocks, else null
+    int dil;                                    // dilation of a 3x3 (0 = 1); conv_igemm only - the U^2-Net path (pad = dil there)
 };
 
 struct DwParams {
@@ -219,6 +220,7 @@ __device__ __forceinline__ void silu4_packed(float* v) {
 
 // launches (implemented in the .hip files); dtype selects the template instance
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st);
+hipError_t launch_conv_igemm(const ConvParams& p, int dtype, hipStream_t st);   // always the register-staged kernel (dilation, ReLU, any Cin % 8 == 0)
 const char* conv_kernel_name(const ConvParams& p, int dtype);
 hipError_t launch_conv_dma(const ConvParams& p, hipStream_t st);
 bool conv_dma_supported(const ConvParams& p);

@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int chunk = tid & 3;
     const int HoWo = p.Ho * p.Wo;
+    const int dil = p.dil > 0 ? p.dil : 1;
 
     // ---- per-thread X rows (fixed over the k loop) ---------------------------------------------------
     int hi0[XL], wi0[XL], pbase[XL];
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     auto load_global = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < XL; ++i) {
-            const int hi = hi0[i] + ky, wi = wi0[i] + kx;
+            const int hi = hi0[i] + ky * dil, wi = wi0[i] + kx * dil;
             const bool ok = (ky < p.ks) && ((unsigned)hi < (unsigned)p.H) && ((unsigned)wi < (unsigned)p.W);
             const size_t off = ((size_t)(pbase[i] + hi * p.W + wi) * p.x_stride + p.x_coff + kc) * ES;
 #pragma unroll
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 const int c = co + r;
                 float t = acc[a][b][r] + ((c < p.Cout) ? p.bias[c] : 0.f);
                 if (p.act == ACT_SILU) t = silu(t);
+                else if (p.act == ACT_RELU) t = fmaxf(t, 0.f);
                 v[r] = t;
             }
             if (p.res) {
@@ -302,6 +304,11 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t st) {
         hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 128, 2, 2>), grid, blk, 0, st, p);
     }
     return hipGetLastError();
+}
+
+hipError_t launch_conv_igemm(const ConvParams& p, int dtype, hipStream_t st) {
+    if (dtype == DT_BF16) return launch_conv_t<__bf16>(p, st);
+    return launch_conv_t<float>(p, st);
 }
 
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st) {

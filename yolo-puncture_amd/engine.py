@@ -92,7 +92,9 @@ EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_we
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
            "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_host_selftest", "yp_letterbox",
-           "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy"]
+           "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy",
+           "yp_u2net_create", "yp_u2net_destroy", "yp_u2net_weight_count", "yp_u2net_weight_info", "yp_u2net_set_weight", "yp_u2net_finalize",
+           "yp_u2net_forward", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
 
 
 def _stream_ptr(device: torch.device) -> int:
