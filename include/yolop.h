@@ -102,6 +102,18 @@ int yp_masks(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev
 int yp_id_mask_resized(yp_engine* e, int b, const float* coeff_dev, const float* boxes_dev, int n, int oh, int ow, int rh,
                        int rw, int64_t* id_out, int32_t* kept_out, int suppress_small, int min_area, void* stream);
 
+/* `results[0].masks.xy[i]` and `get_coord_min_rect_len(...)` on the device (yolo_seg/app.py:101-103, yolo_seg/utils/mask_tools.py:12-22;
+ * [U] Masks.xy = masks2segments(strategy="largest"): cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE), the contour with the most
+ * points; get_coord_min_rect_len = cv2.minAreaRect of that polygon -> (long side, long/short)). Engine-free. Per mask (one workgroup):
+ * bit image of the mask's bounding box in LDS, Moore trace of every blob's outer border, run end points of the longest one, convex
+ * hull, rotating calipers.
+ *    masks_dev uint8 [n,H,W] (non-zero = set)
+ *    pts_out   int32 [n,max_pts,2] (x,y) polygon in mask pixels       count_out int32 [n]: number of points; 0 = empty mask;
+ *              -1 = bounding box larger than the LDS image (1280x720 fits), -2 = more than max_pts points: use the host path
+ *    rect_out  double [n,2] = (long side, short side) of the minimum-area rectangle of the polygon (may be NULL) */
+int yp_mask_contours(const uint8_t* masks_dev, int n, int H, int W, int max_pts, int32_t* pts_out, int32_t* count_out,
+                     double* rect_out, void* stream);
+
 /* LetterBox on the device (the step before the network inside `.predict`; reference call sites yolo_seg/app.py:86-91,
  * [U] ultralytics LetterBox = cv2.resize INTER_LINEAR + cv2.copyMakeBorder(114)). Engine-free, pure function of its
  * arguments; bit-exact with the fixed-point 8-bit bilinear resize the oracle restates.

@@ -1,0 +1,132 @@
+"""yp_mask_contours (HIP: bit image in LDS, parallel Moore traces, hull, rotating calipers) against the host restatement of what the
+reference does with a mask per frame (yolo_seg/app.py:101-103: masks.xy[best] -> get_coord_min_rect_len): the polygon is integer work
+and must be identical point for point; the rectangle is float64 and is also checked against an independent brute-force form."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rand_image
+from yolo_puncture_amd import hostops
+from yolo_puncture_amd.engine import mask_contours_device
+
+pytestmark = pytest.mark.gpu
+
+
+def _blobs(h, w, seed, thr=0.55, cells=9):
+    g = torch.Generator().manual_seed(seed)
+    f = torch.rand(1, 1, cells, cells, generator=g)
+    m = torch.nn.functional.interpolate(f, size=(h, w), mode="bicubic", align_corners=False)[0, 0]
+    return (m > thr).numpy().astype(np.uint8)
+
+
+def _rot_rect(h, w, cx, cy, a, b, ang):
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    c, s = np.cos(ang), np.sin(ang)
+    u = (xx - cx) * c + (yy - cy) * s
+    v = -(xx - cx) * s + (yy - cy) * c
+    return ((np.abs(u) <= a) & (np.abs(v) <= b)).astype(np.uint8)
+
+
+def _brute_min_rect(points):
+    """independent form: hull from scipy's qhull, then every hull edge direction by explicit rotation of ALL points"""
+    from scipy.spatial import ConvexHull
+    p = np.unique(np.asarray(points, dtype=np.float64).reshape(-1, 2), axis=0)
+    if len(p) < 3 or np.linalg.matrix_rank(p - p[0]) < 2:
+        d = p.max(0) - p.min(0) if len(p) else np.zeros(2)
+        # collinear: length = extent along the line
+        if len(p) >= 2:
+            q = p[np.argsort(p @ (p[-1] - p[0] + 1e-300))]
+            return float(np.hypot(*(q[-1] - q[0]))), 0.0
+        return 0.0, 0.0
+    hv = p[ConvexHull(p).vertices]
+    best = None
+    for i in range(len(hv)):
+        e = hv[(i + 1) % len(hv)] - hv[i]
+        t = np.arctan2(e[1], e[0])
+        R = np.array([[np.cos(t), np.sin(t)], [-np.sin(t), np.cos(t)]])
+        q = p @ R.T
+        w, h = q[:, 0].max() - q[:, 0].min(), q[:, 1].max() - q[:, 1].min()
+        if best is None or w * h < best[0]:
+            best = (w * h, max(w, h), min(w, h))
+    return best[1], best[2]
+
+
+def _cases():
+    c = []
+    for seed in range(6):
+        c.append((f"blobs{seed}", _blobs(96 + 7 * seed, 130 + 11 * seed, seed)))
+    c.append(("blobs_720p", _blobs(720, 1280, 42, thr=0.6, cells=13)))
+    c.append(("full_720p", np.ones((720, 1280), np.uint8)))
+    for k, ang in enumerate((0.0, 0.3, 0.785398, 1.2, 1.5707963)):
+        c.append((f"rect{k}", _rot_rect(200, 260, 130.2, 99.7, 70.0, 9.0, ang)))
+    m = np.zeros((64, 80), np.uint8)
+    c.append(("empty", m.copy()))
+    m1 = m.copy(); m1[10, 20] = 1
+    c.append(("one_pixel", m1))
+    m2 = m.copy(); m2[10, 20:22] = 1
+    c.append(("two_pixels", m2))
+    m3 = m.copy(); m3[5, 3:70] = 1
+    c.append(("hline", m3))
+    m4 = m.copy()
+    for i in range(40):
+        m4[5 + i, 10 + i] = 1
+    c.append(("diag_line", m4))
+    m5 = m.copy(); m5[8:50, 8:70] = 1; m5[15:40, 15:60] = 0; m5[20:30, 25:40] = 1; m5[24, 30] = 0     # ring, blob inside the hole, hole inside that
+    c.append(("nested", m5))
+    m6 = m.copy(); m6[0, :] = 1; m6[:, 0] = 1; m6[63, :] = 1; m6[:, 79] = 1                              # frame touching every border
+    c.append(("border_frame", m6))
+    m7 = (np.indices((64, 80)).sum(0) % 2).astype(np.uint8)                                            # checkerboard: one 8-connected blob, thousands of candidates
+    c.append(("checker", m7))
+    m8 = m.copy(); m8[::4, ::4] = 1                                                                    # 320 isolated pixels
+    c.append(("dots", m8))
+    m9 = m.copy(); m9[20:40, 30] = 1; m9[30, 10:60] = 1                                                # a cross: thin arms are traced out and back
+    c.append(("cross", m9))
+    return c
+
+
+@pytest.mark.parametrize("name,mask", _cases(), ids=[n for n, _ in _cases()])
+def test_contour_and_rect_match_host(name, mask):
+    polys, rect = mask_contours_device(torch.from_numpy(mask)[None].cuda(), max_pts=8192)
+    want = hostops.largest_external_contour(mask.astype(bool))
+    got = polys[0]
+    assert got is not None, "the device path must handle this mask"
+    assert got.dtype == np.int32 and got.shape == want.shape, (got.shape, want.shape)
+    assert np.array_equal(got, want)                                       # integer work: identical, point for point, same order
+    wl, ww = hostops.min_area_rect_size(want) if want.shape[0] else (0.0, 0.0)
+    assert rect[0, 0] == pytest.approx(wl, rel=1e-12, abs=1e-12) and rect[0, 1] == pytest.approx(ww, rel=1e-12, abs=1e-9)
+    if want.shape[0] >= 3:
+        bl, bw = _brute_min_rect(want)
+        assert rect[0, 0] == pytest.approx(bl, rel=1e-9, abs=1e-9) and rect[0, 1] == pytest.approx(bw, rel=1e-9, abs=1e-7)
+
+
+def test_batch_of_masks_and_fallback_codes():
+    ms = np.stack([_blobs(120, 160, s) for s in range(5)] + [np.zeros((120, 160), np.uint8)])
+    polys, rect = mask_contours_device(torch.from_numpy(ms).cuda())
+    for i in range(6):
+        assert np.array_equal(polys[i], hostops.largest_external_contour(ms[i].astype(bool)))
+    assert polys[5].shape == (0, 2) and rect[5, 0] == 0.0
+    # too many points for the caller's buffer -> the device pass declines (host path takes over in Masks.xy)
+    polys, _ = mask_contours_device(torch.from_numpy((np.indices((64, 80)).sum(0) % 2).astype(np.uint8))[None].cuda(), max_pts=16)
+    assert polys[0] is None
+    # a blob wider than the LDS image (bounding box 2200 x 900 > 126 KB of bits) -> declined, not wrong
+    big = np.zeros((900, 2200), np.uint8); big[10:890, 5:2195] = 1
+    polys, _ = mask_contours_device(torch.from_numpy(big)[None].cuda())
+    assert polys[0] is None
+
+
+def test_masks_xy_uses_the_device_path_and_matches_host():
+    from yolo_puncture_amd.predictor import Masks
+    ms = np.stack([_blobs(180, 240, s) for s in range(3)])
+    dev = Masks(torch.from_numpy(ms).cuda().float(), (180, 240), u8=torch.from_numpy(ms).cuda())
+    host = Masks(torch.from_numpy(ms).float(), (180, 240))
+    for a, b in zip(dev.xy, host.xy):
+        assert a.dtype == np.float32 and np.array_equal(a, b)
+    for i in range(3):
+        l, r = dev.min_rect_len(i)
+        hl, hr = hostops.get_coord_min_rect_len(host.xy[i])
+        assert l == pytest.approx(hl, rel=1e-12) and r == pytest.approx(hr, rel=1e-9)
+    # masks at the letterboxed size (retina_masks=False): polygons are scaled to the original frame on the host, as ultralytics does
+    dev2 = Masks(torch.from_numpy(ms).cuda().float(), (360, 480), u8=torch.from_numpy(ms).cuda())
+    host2 = Masks(torch.from_numpy(ms).float(), (360, 480))
+    for a, b in zip(dev2.xy, host2.xy):
+        assert np.array_equal(a, b)

@@ -1,0 +1,346 @@
+// Masks.xy + the shaft-length rectangle on the GPU: what the reference's video loop does with every frame's best mask,
+//     coord_xy = results[0].masks.xy[best]                 (yolo_seg/app.py:101; [U] masks2segments(strategy="largest") = cv2.findContours
+//                                                            RETR_EXTERNAL / CHAIN_APPROX_SIMPLE, the contour with the most points)
+//     rect_len, ratio = get_coord_min_rect_len(coord_xy)    (yolo_seg/app.py:102-103; yolo_seg/utils/mask_tools.py:12-22 = cv2.minAreaRect)
+// without the full-resolution mask ever leaving HBM. One workgroup per mask:
+//   1. bounding box of the set pixels (masks are zero outside their detection box), bit image of that box in LDS (one zero word / row around it)
+//   2. candidate starts = set pixels whose W, NW, N, NE neighbours are clear (word-parallel bit logic). The raster-first pixel of every
+//      8-connected blob is one; other candidates sit on hole borders or are later local tops of a blob's outer border
+//   3. every candidate is Moore-traced by its own lane (3x3 neighbourhood = six LDS words fetched together, next direction by bit
+//      rotation + ctz; Jacob's stopping criterion). A trace that meets a pixel earlier in raster order than its start is not a blob's
+//      outer border from its first pixel and is dropped - no connected-component labelling is needed. The survivors are exactly the
+//      traces hostops.largest_external_contour makes; the one with the most CHAIN_APPROX_SIMPLE points wins (ties: first in raster order)
+//   4. the winner is traced once more, emitting the run end points; per-column min/max of those points -> Andrew's monotone chain on at
+//      most 2 points per column (exact integer cross products) -> rotating calipers over the hull edges in float64.
+#include "common.h"
+#include <cstdio>
+
+namespace yp {
+
+constexpr int CT_THREADS = 1024;
+constexpr int CT_MAXCAND = 6144;
+constexpr int CT_BITMAP_BYTES = 126 * 1024;        // a whole 1280x720 frame fits (722 rows x 43 words)
+constexpr int CT_MAXCOL = 2048;            // hull column tables
+
+struct ContourParams {
+    const uint8_t* masks;      // [n][H][W], non-zero = set
+    int n, H, W;
+    int max_pts;
+    int32_t* pts;              // [n][max_pts][2] (x, y) of the winning contour's run end points
+    int32_t* count;            // [n] number of points (0: empty mask ; -1: bounding box too large for the LDS image ; -2: more than max_pts points / candidates)
+    double* rect;              // [n][2] (long side, short side) of the minimum-area rectangle of those points, or null
+};
+
+// clockwise from east, as hostops._DIRS: (dy,dx)
+__device__ __constant__ int c_dy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
+__device__ __constant__ int c_dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+
+struct Bitmap {
+    const unsigned* w;   // LDS
+    int pitch;           // words per row
+    // 8-neighbour mask of pixel (y,x) in image-local coordinates (row y lives at y+1, column x at bit x+32)
+    __device__ __forceinline__ unsigned nb(int y, int x) const {
+        const int pos = x + 31;                              // bit position of x-1
+        const int j = pos >> 5, sh = pos & 31;
+        const unsigned* r0 = w + (size_t)y * pitch + j;      // row above (y-1 -> stored row y)
+        const unsigned long long u = ((unsigned long long)r0[1] << 32) | r0[0];
+        const unsigned long long m = ((unsigned long long)r0[pitch + 1] << 32) | r0[pitch];
+        const unsigned long long d = ((unsigned long long)r0[2 * pitch + 1] << 32) | r0[2 * pitch];
+        const unsigned uu = (unsigned)(u >> sh) & 7u, mm = (unsigned)(m >> sh) & 7u, dd = (unsigned)(d >> sh) & 7u;
+        // E, SE, S, SW, W, NW, N, NE
+        return ((mm >> 2) & 1u) | (((dd >> 2) & 1u) << 1) | (((dd >> 1) & 1u) << 2) | ((dd & 1u) << 3) | ((mm & 1u) << 4) | ((uu & 1u) << 5) |
+               (((uu >> 1) & 1u) << 6) | (((uu >> 2) & 1u) << 7);
+    }
+};
+
+// One Moore trace from (sy,sx). EMIT = false: returns the number of CHAIN_APPROX_SIMPLE points (0 = dropped: met an earlier pixel, or
+// longer than the step bound). EMIT = true: also writes the points (global, then bounding-box origin added).
+template <bool EMIT>
+__device__ int moore_trace(const Bitmap& bm, int bw, int sy, int sx, int max_steps, int32_t* out, int max_pts, int ox, int oy) {
+    const int start_lin = sy * bw + sx;
+    int cy = sy, cx = sx, d = 6;                 // "arrived" from the north-west side: start searching at north
+    int start_d = -1, prev_move = -1, first_move = -1;
+    int npts = 1, nkeep = 0;
+    int px = sx, py = sy;                        // the point whose keep decision is pending: it is kept iff the moves before and after differ
+    for (int step = 0; step < max_steps; ++step) {
+        const unsigned nbm = bm.nb(cy, cx);
+        if (nbm == 0) {                           // isolated pixel
+            if (EMIT) { out[0] = sx + ox; out[1] = sy + oy; }
+            return 1;
+        }
+        const unsigned rot = ((nbm >> d) | (nbm << (8 - d))) & 0xffu;
+        const int nd = (d + __builtin_ctz(rot)) & 7;
+        if (start_d < 0) start_d = nd;
+        else if (cy == sy && cx == sx && nd == start_d) {
+            // closed: pts[:-1] drops the repeated start, n = npts - 1 points, moves m_0..m_{n-1} (the last one returned to the start)
+            const int n = npts - 1;
+            if (n <= 2) {                         // _compress keeps everything
+                if (EMIT) {
+                    out[0] = sx + ox; out[1] = sy + oy;
+                    if (n == 2) { out[2] = sx + c_dx[first_move] + ox; out[3] = sy + c_dy[first_move] + oy; }
+                }
+                return n;
+            }
+            // point 0 is kept iff the last move differs from the first one; the pending point (the start, reached by prev_move) is point 0
+            if (prev_move != first_move) {
+                if (EMIT) {
+                    // point 0 must come first in the output: it was not emitted at the beginning, so the list is rotated by one here
+                    if (nkeep < max_pts) { out[2 * nkeep] = sx + ox; out[2 * nkeep + 1] = sy + oy; }
+                }
+                ++nkeep;
+                return EMIT ? -nkeep : nkeep;     // (EMIT: negative = "rotate right by one", see the caller)
+            }
+            return nkeep > 0 ? nkeep : 1;         // (all moves equal cannot happen on a closed trace; _compress would keep pts[0])
+        }
+        // take the move
+        if (first_move < 0) first_move = nd;
+        else if (nd != prev_move) {               // the point we are leaving (px,py) had a different move before it: kept
+            if (EMIT && nkeep < max_pts) { out[2 * nkeep] = px + ox; out[2 * nkeep + 1] = py + oy; }
+            ++nkeep;
+        }
+        prev_move = nd;
+        cy += c_dy[nd]; cx += c_dx[nd];
+        px = cx; py = cy;
+        ++npts;
+        if (cy * bw + cx < start_lin) return 0;  // not the raster-first pixel of its blob's outer border
+        d = (nd & 1) ? ((nd + 5) & 7) : ((nd + 6) & 7);   // restart at the background pixel examined last
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ int s_box[4];                 // x0, y0, x1, y1 (inclusive)
+    __shared__ int s_ncand;
+    __shared__ unsigned long long s_best;    // (points << 32) | ~start_lin
+    __shared__ int s_np, s_nhull;
+    const int mi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint8_t* M = p.masks + (size_t)mi * p.H * p.W;
+    if (tid == 0) { s_box[0] = p.W; s_box[1] = p.H; s_box[2] = -1; s_box[3] = -1; s_ncand = 0; s_best = 0ull; s_np = 0; s_nhull = 0; }
+    __syncthreads();
+    // ---- 1a. bounding box -------------------------------------------------------------------------------------------
+    {
+        int x0 = p.W, y0 = p.H, x1 = -1, y1 = -1;
+        const size_t npix = (size_t)p.H * p.W;
+        for (size_t i = (size_t)tid * 16; i < npix; i += (size_t)CT_THREADS * 16) {
+            // 16 pixels per step (rows are not 16-aligned in general: byte loads through a 16-byte window when aligned, else scalar)
+            unsigned any = 0;
+            const size_t e = min(i + 16, npix);
+            if (((uintptr_t)(M + i) & 15) == 0 && e == i + 16) {
+                const uint4 v = *(const uint4*)(M + i);
+                any = v.x | v.y | v.z | v.w;
+            } else {
+                for (size_t k = i; k < e; ++k) any |= M[k];
+            }
+            if (any)
+                for (size_t k = i; k < e; ++k)
+                    if (M[k]) {
+                        const int y = (int)(k / p.W), x = (int)(k - (size_t)y * p.W);
+                        x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
+                    }
+        }
+        if (x1 >= 0) { atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0); atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1); }
+    }
+    __syncthreads();
+    const int bx0 = s_box[0], by0 = s_box[1], bx1 = s_box[2], by1 = s_box[3];
+    if (bx1 < 0) {                            // empty mask
+        if (tid == 0) { p.count[mi] = 0; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
+        return;
+    }
+    const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
+    const int pitch = (bw + 31) / 32 + 3;     // one zero word left, one right, one for the 64-bit window's overrun
+    if ((size_t)(bh + 2) * pitch * 4 > (size_t)CT_BITMAP_BYTES || bw > CT_MAXCOL) {
+        if (tid == 0) { p.count[mi] = -1; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
+        return;
+    }
+    unsigned* bmw = (unsigned*)smem;
+    int* cand = (int*)(smem + CT_BITMAP_BYTES);
+    // ---- 1b. bit image --------------------------------------------------------------------------------------------------
+    for (int i = tid; i < (bh + 2) * pitch; i += CT_THREADS) bmw[i] = 0u;
+    __syncthreads();
+    for (int y = wave; y < bh; y += CT_THREADS / 64) {
+        const uint8_t* row = M + (size_t)(by0 + y) * p.W + bx0;
+        for (int x = 0; x < bw; x += 64) {
+            const int xx = x + lane;
+            const unsigned long long b = __ballot(xx < bw && row[xx] != 0);
+            if (lane == 0) {
+                unsigned* dst = bmw + (size_t)(y + 1) * pitch + 1 + (x >> 5);
+                dst[0] = (unsigned)b;
+                if (x + 32 < bw) dst[1] = (unsigned)(b >> 32);
+            }
+        }
+    }
+    __syncthreads();
+    Bitmap bm{bmw, pitch};
+    // ---- 2. candidates ----------------------------------------------------------------------------------------------------
+    const int words_per_row = (bw + 31) / 32;
+    for (int i = tid; i < bh * words_per_row; i += CT_THREADS) {
+        const int y = i / words_per_row, j = i - y * words_per_row + 1;
+        const unsigned* r = bmw + (size_t)(y + 1) * pitch;
+        const unsigned* u = r - pitch;
+        const unsigned m = r[j];
+        if (!m) continue;
+        const unsigned wb = (m << 1) | (r[j - 1] >> 31);
+        const unsigned ub = u[j];
+        const unsigned nwb = (ub << 1) | (u[j - 1] >> 31);
+        const unsigned neb = (ub >> 1) | (u[j + 1] << 31);
+        unsigned c = m & ~wb & ~ub & ~nwb & ~neb;
+        while (c) {
+            const int b = __builtin_ctz(c);
+            c &= c - 1;
+            const int k = atomicAdd(&s_ncand, 1);
+            if (k < CT_MAXCAND) cand[k] = y * bw + (j - 1) * 32 + b;
+        }
+    }
+    __syncthreads();
+    const int ncand = s_ncand;
+    if (ncand > CT_MAXCAND) {
+        if (tid == 0) { p.count[mi] = -2; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
+        return;
+    }
+    // ---- 3. trace every candidate -------------------------------------------------------------------------------------------
+    const int max_steps = 4 * bh * bw + 8;
+    for (int k = tid; k < ncand; k += CT_THREADS) {
+        const int lin = cand[k];
+        const int sy = lin / bw, sx = lin - sy * bw;
+        const int np = moore_trace<false>(bm, bw, sy, sx, max_steps, nullptr, 0, 0, 0);
+        if (np > 0) atomicMax(&s_best, ((unsigned long long)(unsigned)np << 32) | (unsigned)(~(unsigned)lin));
+    }
+    __syncthreads();
+    // ---- 4. the winner's points, hull, rectangle ------------------------------------------------------------------------------
+    const unsigned long long best = s_best;
+    const int np_best = (int)(best >> 32);
+    int32_t* out = p.pts + (size_t)mi * p.max_pts * 2;
+    if (np_best > p.max_pts || np_best <= 0) {
+        if (tid == 0) { p.count[mi] = np_best > 0 ? -2 : 0; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
+        return;
+    }
+    if (tid == 0) {
+        const int lin = (int)(~(unsigned)(best & 0xffffffffull));
+        const int sy = lin / bw, sx = lin - sy * bw;
+        int np = moore_trace<true>(bm, bw, sy, sx, max_steps, out, p.max_pts, bx0, by0);
+        if (np < 0) {                         // point 0 was appended last: rotate the list right by one so that it leads, as _compress orders it
+            np = -np;
+            const int lx = out[2 * (np - 1)], ly = out[2 * (np - 1) + 1];
+            for (int i = np - 1; i > 0; --i) { out[2 * i] = out[2 * (i - 1)]; out[2 * i + 1] = out[2 * (i - 1) + 1]; }
+            out[0] = lx; out[1] = ly;
+        }
+        p.count[mi] = np;
+        s_np = np;
+        __threadfence_block();
+    }
+    __syncthreads();                          // (the bit image is dead from here on: its LDS becomes the hull's tables)
+    if (!p.rect) return;
+    const int np = s_np;
+    int* colmin = (int*)smem;
+    int* colmax = colmin + CT_MAXCOL;
+    int* hull = colmax + CT_MAXCOL;           // up to 2 * CT_MAXCOL + 2 vertices, (x, y) interleaved
+    static_assert((size_t)(2 * CT_MAXCOL + 2 * (2 * CT_MAXCOL + 2)) * sizeof(int) <= (size_t)CT_BITMAP_BYTES, "hull tables fit the bit image's LDS");
+    for (int i = tid; i < bw; i += CT_THREADS) { colmin[i] = 0x7fffffff; colmax[i] = -1; }
+    __syncthreads();
+    for (int i = tid; i < np; i += CT_THREADS) {
+        const int x = out[2 * i] - bx0, y = out[2 * i + 1];
+        atomicMin(&colmin[x], y);
+        atomicMax(&colmax[x], y);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // Andrew's monotone chain over (x, colmin[x]), (x, colmax[x]) in (x, y) order: lower chain left->right, upper chain right->left;
+        // pops on cross <= 0 (no collinear vertices) - the points of a column between its extremes are popped by the full algorithm
+        // too, so this is exactly hostops._convex_hull on the unique points
+        int n = 0;
+        auto cross_le0 = [&](int ax, int ay, int bx, int by, int qx, int qy) {
+            return (long long)(bx - ax) * (qy - ay) - (long long)(by - ay) * (qx - ax) <= 0;
+        };
+        int nuniq = 0, fx = 0, fy = 0, gx = 0, gy = 0;
+        for (int x = 0; x < bw; ++x)
+            if (colmax[x] >= 0) {
+                if (nuniq == 0) { fx = x; fy = colmin[x]; }
+                nuniq += (colmin[x] != colmax[x]) ? 2 : 1;
+                gx = x; gy = colmax[x];
+            }
+        if (nuniq <= 2) {
+            hull[0] = fx; hull[1] = fy; n = 1;
+            if (nuniq == 2) { hull[2] = gx; hull[3] = gy; n = 2; }
+        } else {
+            auto push = [&](int qx, int qy, int base) {
+                while (n - base >= 2 && cross_le0(hull[2 * (n - 2)], hull[2 * (n - 2) + 1], hull[2 * (n - 1)], hull[2 * (n - 1) + 1], qx, qy)) --n;
+                hull[2 * n] = qx; hull[2 * n + 1] = qy; ++n;
+            };
+            for (int x = 0; x < bw; ++x)
+                if (colmax[x] >= 0) {
+                    push(x, colmin[x], 0);
+                    if (colmax[x] != colmin[x]) push(x, colmax[x], 0);
+                }
+            --n;                                  // lo[:-1]
+            const int base = n;
+            for (int x = bw - 1; x >= 0; --x)
+                if (colmax[x] >= 0) {
+                    if (colmax[x] != colmin[x]) push(x, colmax[x], base);
+                    push(x, colmin[x], base);
+                }
+            --n;                                  // up[:-1]
+        }
+        s_nhull = n;
+    }
+    __syncthreads();
+    const int nh = s_nhull;
+    if (nh <= 2) {
+        if (tid == 0) {
+            double len = 0.0;
+            if (nh == 2) { const double ddx = hull[2] - hull[0], ddy = hull[3] - hull[1]; len = hypot(ddx, ddy); }
+            p.rect[2 * mi] = len; p.rect[2 * mi + 1] = 0.0;
+        }
+        return;
+    }
+    // rotating calipers: one hull edge per thread, float64 as hostops.min_area_rect_size (u = e/|e|, v = (-u.y, u.x), extents of the
+    // projections); the smallest area wins, ties by the lower edge index (the host loop keeps the first minimum)
+    __shared__ double s_area[CT_THREADS / 64], s_w[CT_THREADS / 64], s_h[CT_THREADS / 64];
+    __shared__ int s_idx[CT_THREADS / 64];
+    double barea = 1e300, bwid = 0, bhei = 0;
+    int bidx = 0x7fffffff;
+    for (int i = tid; i < nh; i += CT_THREADS) {
+        const int j = (i + 1 == nh) ? 0 : i + 1;
+        const double ex = (double)(hull[2 * j] - hull[2 * i]), ey = (double)(hull[2 * j + 1] - hull[2 * i + 1]);
+        const double nrm = hypot(ex, ey);
+        const double ux = ex / nrm, uy = ey / nrm;
+        const double vx = -uy, vy = ux;
+        double amin = 1e300, amax = -1e300, bmin = 1e300, bmax = -1e300;
+        for (int k = 0; k < nh; ++k) {
+            const double hx = (double)(hull[2 * k] + bx0), hy = (double)hull[2 * k + 1];
+            const double a = hx * ux + hy * uy, b = hx * vx + hy * vy;
+            amin = fmin(amin, a); amax = fmax(amax, a); bmin = fmin(bmin, b); bmax = fmax(bmax, b);
+        }
+        const double w = amax - amin, h = bmax - bmin;
+        if (w * h < barea || (w * h == barea && i < bidx)) { barea = w * h; bwid = w; bhei = h; bidx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const double oa = __shfl_xor(barea, o), ow = __shfl_xor(bwid, o), oh = __shfl_xor(bhei, o);
+        const int oi = __shfl_xor(bidx, o);
+        if (oa < barea || (oa == barea && oi < bidx)) { barea = oa; bwid = ow; bhei = oh; bidx = oi; }
+    }
+    if (lane == 0) { s_area[wave] = barea; s_w[wave] = bwid; s_h[wave] = bhei; s_idx[wave] = bidx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int k = 1; k < CT_THREADS / 64; ++k)
+            if (s_area[k] < barea || (s_area[k] == barea && s_idx[k] < bidx)) { barea = s_area[k]; bwid = s_w[k]; bhei = s_h[k]; bidx = s_idx[k]; }
+        p.rect[2 * mi] = fmax(bwid, bhei); p.rect[2 * mi + 1] = fmin(bwid, bhei);
+    }
+}
+
+hipError_t launch_contours(const uint8_t* masks, int n, int H, int W, int max_pts, int32_t* pts, int32_t* count, double* rect, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    ContourParams p{masks, n, H, W, max_pts, pts, count, rect};
+    const size_t sh = (size_t)CT_BITMAP_BYTES + (size_t)CT_MAXCAND * sizeof(int);
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)contour_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(contour_kernel, dim3(n), dim3(CT_THREADS), sh, st, p);
+    return hipGetLastError();
+}
+
+}  // namespace yp

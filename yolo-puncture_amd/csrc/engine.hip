@@ -1529,6 +1529,14 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     return YP_OK;
 }
 
+int yp_mask_contours(const uint8_t* masks_dev, int n, int H, int W, int max_pts, int32_t* pts_out, int32_t* count_out, double* rect_out, void* stream) {
+    if (n < 0 || H <= 0 || W <= 0 || max_pts <= 0) return fail(YP_ERR_ARG, "yp_mask_contours: bad sizes");
+    if (n > 0 && (!masks_dev || !pts_out || !count_out)) return fail(YP_ERR_ARG, "yp_mask_contours: null buffer");
+    if ((long)H * W >= (1l << 31)) return fail(YP_ERR_ARG, "yp_mask_contours: image too large");
+    HIPCHK(launch_contours(masks_dev, n, H, W, max_pts, pts_out, count_out, rect_out, (hipStream_t)stream));
+    return YP_OK;
+}
+
 int yp_letterbox(const uint8_t* src_dev, int h0, int w0, uint8_t* dst_dev, int out_h, int out_w, int new_h, int new_w, int top, int left,
                  int pad_value, void* stream) {
     if (!src_dev || !dst_dev) return fail(YP_ERR_ARG, "yp_letterbox: null buffer");

@@ -53,6 +53,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_masks.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp]
     lib.yp_id_mask_resized.argtypes = [vp, C.c_int, vp, vp] + [C.c_int] * 5 + [vp, vp, C.c_int, C.c_int, vp]
     lib.yp_id_mask_resized.restype = C.c_int
+    lib.yp_mask_contours.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.yp_mask_contours.restype = C.c_int
     lib.yp_plan.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     lib.yp_op_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.yp_op_output.argtypes = [vp, C.c_int, ip, ip, ip]
@@ -91,7 +93,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_host_selftest", "yp_letterbox",
+           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy",
            "yp_u2net_create", "yp_u2net_destroy", "yp_u2net_weight_count", "yp_u2net_weight_info", "yp_u2net_set_weight", "yp_u2net_finalize",
            "yp_u2net_forward", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
@@ -119,6 +121,30 @@ def letterbox_device(src: torch.Tensor, geo: dict, out: Optional[torch.Tensor] =
     if rc != 0:
         raise YolopError(lib.yp_last_error().decode())
     return out
+
+
+def mask_contours_device(masks: torch.Tensor, max_pts: int = 4096, want_rect: bool = True):
+    """yp_mask_contours: uint8 cuda [n,H,W] -> (list of int32 [m,2] numpy polygons (None where the device path declined), rect float64 [n,2]
+    numpy (long side, short side) or None). One small D2H of the points; the masks stay on the device."""
+    if not (masks.is_cuda and masks.dtype == torch.uint8 and masks.dim() == 3):
+        raise ValueError("mask_contours_device needs a uint8 CUDA tensor [n,H,W]")
+    masks = masks.contiguous()
+    n, H, W = (int(v) for v in masks.shape)
+    dev = masks.device
+    pts = torch.empty((n, max_pts, 2), dtype=torch.int32, device=dev)
+    cnt = torch.empty((n,), dtype=torch.int32, device=dev)
+    rect = torch.empty((n, 2), dtype=torch.float64, device=dev) if want_rect else None
+    lib = load_library()
+    with torch.cuda.device(dev):
+        rc = lib.yp_mask_contours(C.c_void_p(masks.data_ptr()), n, H, W, int(max_pts), C.c_void_p(pts.data_ptr()), C.c_void_p(cnt.data_ptr()),
+                                  C.c_void_p(rect.data_ptr() if rect is not None else None), C.c_void_p(_stream_ptr(dev)))
+    if rc != 0:
+        raise YolopError(lib.yp_last_error().decode())
+    c = cnt.cpu().numpy()
+    top = int(max(1, c.max())) if n else 1
+    host = pts[:, :top].cpu().numpy()
+    polys = [host[i, :c[i]].copy() if c[i] >= 0 else None for i in range(n)]
+    return polys, (rect.cpu().numpy() if rect is not None else None)
 
 
 class Engine:

@@ -20,7 +20,7 @@ import numpy as np
 import torch
 
 from . import hostops
-from .engine import Engine, letterbox_device
+from .engine import Engine, letterbox_device, mask_contours_device
 from .weights import read_ultralytics_pt, synthetic_state
 
 _ENGINE_CACHE: Dict[tuple, Engine] = {}
@@ -103,21 +103,26 @@ class Boxes:
 
 class Masks:
     """.data: float {0,1} [n,H,W] (H,W = original image when retina_masks else the letterboxed input);
-    .xy: one float32 [m,2] polygon per mask (largest external contour, pixels of the original image)."""
+    .xy: one float32 [m,2] polygon per mask (largest external contour, pixels of the original image).
+    When the masks live on the GPU the contour, its convex hull and the minimum-area rectangle are computed there
+    (yp_mask_contours) and only the polygon's few hundred points travel to the host; `.min_rect` is the rectangle
+    `get_coord_min_rect_len` would derive from `.xy[i]` (reference yolo_seg/app.py:101-103)."""
 
-    def __init__(self, data: torch.Tensor, orig_shape: Tuple[int, int]):
+    def __init__(self, data: torch.Tensor, orig_shape: Tuple[int, int], u8: Optional[torch.Tensor] = None):
         self.data = data
         self.orig_shape = tuple(orig_shape)
+        self._u8 = u8                     # the engine's uint8 masks (same pixels as data), kept for the device contour pass
         self._xy = None
+        self._rect = None
 
     def cpu(self):
-        m = Masks(self.data.cpu(), self.orig_shape)
-        m._xy = self._xy
+        m = Masks(self.data.cpu(), self.orig_shape, self._u8)
+        m._xy, m._rect = self._xy, self._rect
         return m
 
     def numpy(self):
-        m = Masks(self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else self.data, self.orig_shape)
-        m._xy = self._xy
+        m = Masks(self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else self.data, self.orig_shape, self._u8)
+        m._xy, m._rect = self._xy, self._rect
         return m
 
     def __len__(self):
@@ -125,21 +130,52 @@ class Masks:
 
     def __getitem__(self, i):
         d = self.data[i]
-        return Masks(d[None] if d.ndim == 2 else d, self.orig_shape)
+        u = self._u8[i] if self._u8 is not None else None
+        return Masks(d[None] if d.ndim == 2 else d, self.orig_shape, u[None] if (u is not None and u.dim() == 2) else u)
+
+    def _contours(self):
+        if self._xy is not None:
+            return
+        n = len(self)
+        polys = [None] * n
+        rect = None
+        u8 = self._u8
+        if u8 is None and isinstance(self.data, torch.Tensor) and self.data.is_cuda:
+            u8 = (self.data > 0.5).to(torch.uint8)
+        if u8 is not None and u8.is_cuda and n > 0:
+            polys, rect = mask_contours_device(u8)
+        mh, mw = (int(v) for v in self.data.shape[1:])
+        host = None
+        out = []
+        for i in range(n):
+            poly = polys[i]
+            if poly is None:                              # (no GPU copy, or the device pass declined this mask: host trace)
+                if host is None:
+                    host = self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else np.asarray(self.data)
+                poly = hostops.largest_external_contour(host[i] > 0.5)
+                if rect is not None:
+                    rect[i] = hostops.min_area_rect_size(poly) if poly.shape[0] else (0.0, 0.0)
+            if poly.shape[0] and (mh, mw) != self.orig_shape:
+                poly = hostops.scale_coords((mh, mw), poly, self.orig_shape)
+            out.append(poly.astype(np.float32))
+        self._xy = out
+        self._rect = rect if (mh, mw) == self.orig_shape else None      # (the rectangle is of the polygon in mask pixels)
 
     @property
     def xy(self) -> List[np.ndarray]:
-        if self._xy is None:
-            d = self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else np.asarray(self.data)
-            mh, mw = d.shape[1:]
-            out = []
-            for m in d:
-                poly = hostops.largest_external_contour(m > 0.5)
-                if poly.shape[0] and (mh, mw) != self.orig_shape:
-                    poly = hostops.scale_coords((mh, mw), poly, self.orig_shape)
-                out.append(poly.astype(np.float32))
-            self._xy = out
+        self._contours()
         return self._xy
+
+    def min_rect_len(self, i: int):
+        """(length, length / width) exactly as `get_coord_min_rect_len(self.xy[i])` returns them (yolo_seg/utils/mask_tools.py:12-22),
+        from the device rectangle when there is one."""
+        self._contours()
+        if self._rect is None or len(self._xy[i]) < 3:
+            return hostops.get_coord_min_rect_len(self._xy[i])
+        length, width = float(self._rect[i][0]), float(self._rect[i][1])
+        if width == 0:
+            width = 1
+        return length, length / width
 
 
 class Results:
@@ -303,7 +339,7 @@ class YOLO:
                         m, _, _ = eng.masks(bi, cf, d[:, :4], (oh, ow), retina=True)
                     else:
                         m, _, _ = eng.masks(bi, cf, boxes_in, (H, W), retina=False)
-                    masks = Masks(m.to(torch.float32), (oh, ow))
+                    masks = Masks(m.to(torch.float32), (oh, ow), u8=m)
                 out_by_index[i] = Results(imgs[i], Boxes(d, (oh, ow)), masks, self.names, paths[i])
         for i in range(len(imgs)):
             results.append(out_by_index[i])
