@@ -45,7 +45,14 @@ typedef struct yp_model_desc {
     int task;    /* YP_TASK_DETECT | YP_TASK_SEGMENT (v10 trunk + Proto/cv4 head) */
     int dtype;   /* YP_BF16 | YP_F32                                              */
     int max_det; /* 300 (ultralytics default); top-k size of the one-to-one head  */
+    int family;  /* YP_FAMILY_V10 (0) | YP_FAMILY_V8 | YP_FAMILY_11: which ultralytics yaml the graph follows. The v8 / 11
+                    families (the checkpoints the reference's UI offers, yolo_seg/app.py:218-223) are segment models: task must
+                    be YP_TASK_SEGMENT; their head ends in conf filter + NMS (yp_set_nms) instead of the v10 top-k */
 } yp_model_desc;
+
+#define YP_FAMILY_V10 0
+#define YP_FAMILY_V8 8
+#define YP_FAMILY_11 11
 
 const char* yp_last_error(void);
 
@@ -174,6 +181,11 @@ int yp_tensor_read(yp_engine* e, int i, float* host_out);  /* sync copy NHWC -> 
 /* Run the plan op by op with a HIP event pair around every launch on `stream`; ms_out[#ops]. */
 int yp_profile(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
                float* coeff_out, float* ms_out, int iters, void* stream);
+
+/* NMS heads (families v8 / 11): score threshold and IoU threshold of `ops.non_max_suppression` [U] as `.predict(conf=, iou=)` sets
+ * them (defaults 0.25 / 0.7). Rows of yp_forward's det_out are the boxes NMS keeps, best first; may be changed between forwards
+ * (the values live in device memory: a captured graph does not go stale). No effect on the v10 family. */
+int yp_set_nms(yp_engine* e, float conf, float iou);
 
 /* Enable/disable the plan-time autotuner that picks the conv tile configuration per layer (default on). */
 int yp_set_autotune(yp_engine* e, int enable);

@@ -31,7 +31,7 @@ class _CalibOracle(Oracle):
     position-to-position differences into unit variance at every layer and makes the net chaotic
     (fp32-vs-fp64 box differences of 0.1 px instead of 1e-3 px)."""
 
-    OUT_STD = {"one2one_cv2": 2.0, "one2one_cv3": 1.0, "cv4": 1.0}
+    OUT_STD = {"one2one_cv2": 2.0, "one2one_cv3": 1.0, "cv4": 1.0, "cv2": 2.0, "cv3": 1.0}
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
@@ -44,7 +44,7 @@ class _CalibOracle(Oracle):
             k = w.shape[-1]
             y = F.conv2d(x, w, b, stride=s, padding=k // 2, groups=g)
             parts = name.split(".")
-            if name.startswith("model.23.") and parts[-1] == "2" and parts[2] in self.OUT_STD:
+            if (name.startswith("model.23.") or name.startswith("model.22.cv")) and parts[-1] == "2" and parts[2] in self.OUT_STD:
                 sc = self.OUT_STD[parts[2]] / y.std().clamp_min(1e-6)   # biased nn.Conv2d: keep the configured bias
                 self.w[name] = (w * sc, b)
             else:
@@ -121,3 +121,42 @@ def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     """max |a-b| / (max|b| + tiny): scale-aware error for activation tensors."""
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+# ---- YOLOv8-seg / YOLO11-seg (the families the reference's UI offers) ---------------------------------------------------------
+@functools.lru_cache(maxsize=16)
+def _calibrated_family_cached(family: str, variant: str, nc: int, seed: int, shape: Tuple[int, int, int]):
+    from oracle.yolo_seg_oracle import SegOracle
+    from yolo_puncture_amd.weights import synthetic_state_family
+
+    class _CalibSeg(_CalibOracle, SegOracle):
+        pass
+
+    st = synthetic_state_family(family, variant, nc, seed=seed, cls_bias=-3.0)
+    im = rand_image((shape[0], shape[1], shape[2], 3), seed=seed)
+    co = _CalibSeg(st, family, variant, nc, "fp32")
+    with torch.no_grad():
+        co.forward(im, conf=0.5)
+    out: Dict[str, torch.Tensor] = {}
+    for name, (w, b) in co.w.items():
+        if f"{name}.conv.weight" in st:
+            out[f"{name}.conv.weight"] = w.clone()
+            c2 = w.shape[0]
+            out[f"{name}.bn.weight"] = torch.ones(c2)
+            out[f"{name}.bn.bias"] = b.clone()
+            out[f"{name}.bn.running_mean"] = torch.zeros(c2)
+            out[f"{name}.bn.running_var"] = torch.full((c2,), 1.0 - BN_EPS)
+        else:
+            out[f"{name}.weight"] = w.clone()
+            out[f"{name}.bias"] = b.clone()
+    for k, v in st.items():
+        if k.endswith("dfl.conv.weight"):
+            out[k] = v.clone()
+    assert set(out) == set(st), sorted(set(out) ^ set(st))[:8]
+    return out
+
+
+def make_case_family(family: str, variant: str = "n", nc: int = 80, seed: int = 0, shape: Tuple[int, int, int] = (2, 96, 128)):
+    """-> (calibrated unfused state dict of a `<family><variant>-seg` checkpoint, uint8 frames it was calibrated on)."""
+    st = _calibrated_family_cached(family, variant, nc, seed, tuple(shape))
+    return {k: v.clone() for k, v in st.items()}, rand_image((shape[0], shape[1], shape[2], 3), seed=seed)

@@ -91,3 +91,68 @@ def test_bf16emu_rounds_every_materialised_tensor():
         if n.endswith(".2") and n.startswith("model.23."):
             continue                                    # head logits stay fp32 by design
         assert torch.equal(x, x.to(torch.bfloat16).float()), n
+
+
+# ---- YOLOv8-seg / YOLO11-seg: published model summaries pin the restated structure ------------------------------------------------
+@pytest.mark.parametrize("family,variant,params", [("v8", "n", 3409968), ("11", "n", 2876848)])
+def test_seg_families_match_published_parameter_counts_exactly(family, variant, params):
+    """ultralytics prints 'YOLOv8n-seg summary: ... 3,409,968 parameters' / 'YOLO11n-seg summary: ... 2,876,848 parameters'"""
+    from oracle.yolo_seg_oracle import count_params
+    assert count_params(family, variant) == params
+
+
+@pytest.mark.parametrize("family,variant,millions", [("v8", "s", 11.8), ("v8", "m", 27.3), ("v8", "l", 46.0), ("v8", "x", 71.8),
+                                                     ("11", "s", 10.1), ("11", "m", 22.4), ("11", "l", 27.6), ("11", "x", 62.1)])
+def test_seg_families_match_the_docs_table(family, variant, millions):
+    """the params (M) column of the ultralytics segmentation tables (YOLO11l-seg is listed as 27.6: 27.68 truncated)"""
+    from oracle.yolo_seg_oracle import count_params
+    assert abs(count_params(family, variant) / 1e6 - millions) < 0.09
+
+
+def test_nms_oracle_against_brute_force():
+    """nms_greedy (torchvision.ops.nms restated) == the definition: walk boxes by descending score, keep a box iff its IoU with every
+    box kept so far is <= thr"""
+    import torch
+    from oracle.yolo_seg_oracle import nms_greedy
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 7, 200):
+        xy = torch.rand(n, 2, generator=g) * 100
+        wh = torch.rand(n, 2, generator=g) * 40 + 2
+        boxes = torch.cat((xy, xy + wh), 1)
+        scores = torch.rand(n, generator=g)
+        keep = nms_greedy(boxes, scores, 0.5).tolist()
+        order = sorted(range(n), key=lambda i: (-float(scores[i]), i))
+        want = []
+        for i in order:
+            ok = True
+            for j in want:
+                x1, y1 = max(boxes[i, 0], boxes[j, 0]), max(boxes[i, 1], boxes[j, 1])
+                x2, y2 = min(boxes[i, 2], boxes[j, 2]), min(boxes[i, 3], boxes[j, 3])
+                inter = max(x2 - x1, 0) * max(y2 - y1, 0)
+                a = (boxes[i, 2] - boxes[i, 0]) * (boxes[i, 3] - boxes[i, 1]) + (boxes[j, 2] - boxes[j, 0]) * (boxes[j, 3] - boxes[j, 1]) - inter
+                if inter / a > 0.5:
+                    ok = False
+                    break
+            if ok:
+                want.append(i)
+        assert keep == want
+
+
+@pytest.mark.parametrize("family,variant", [("v8", "n"), ("v8", "x"), ("11", "n"), ("11", "m"), ("11", "x")])
+def test_engine_graph_equals_oracle_layout_for_seg_families(family, variant):
+    """the C++ graph builder (yp_create with family) and the oracle's expected_state agree on every parameter name and shape"""
+    from oracle.yolo_seg_oracle import expected_state
+    from yolo_puncture_amd.engine import Engine
+    from yolo_puncture_amd.weights import fold_state, guess_family, guess_variant_family, synthetic_state_family
+    st = synthetic_state_family(family, variant, 80, 0)
+    assert {k: tuple(v.shape) for k, v in st.items()} == dict(expected_state(family, variant, 80))
+    assert guess_family(st) == family and guess_variant_family(st, family) == variant
+    e = Engine(variant, 80, True, "bf16", 0, family=family)
+    exp = dict(e.expected_weights())
+    got = {}
+    for k, (w, b) in fold_state(st).items():
+        got[k + ".weight"], got[k + ".bias"] = tuple(w.shape), tuple(b.shape)
+    assert exp == got
+    assert e.plan(1, 640, 640)[-1]["kernel"] == "head_nms_kernel"
+    assert e.lib.yp_debug_host_selftest(e._h) > 0
+    e.close()

@@ -17,10 +17,13 @@ int main() {
     const char variants[] = {'n', 's', 'm', 'b', 'l', 'x'};
     const int shapes[][3] = {{1, 64, 64}, {2, 96, 128}, {1, 384, 640}, {32, 640, 640}, {8, 640, 640}, {3, 480, 608}, {1, 640, 480}, {5, 32, 32}};
     long launches = 0;
+    const int families[] = {YP_FAMILY_V10, YP_FAMILY_V8, YP_FAMILY_11};
+    for (int fam : families)
     for (char v : variants)
         for (int task = 0; task < 2; ++task)
             for (int dtype = 0; dtype < 2; ++dtype) {
-                yp_model_desc d{v, 80, task, dtype, 300};
+                if (fam != YP_FAMILY_V10 && (task == 0 || v == 'b' || dtype == 1)) continue;     // the v8 / 11 families: n s m l x, segment
+                yp_model_desc d{v, 80, task, dtype, 300, fam};
                 yp_engine* e = nullptr;
                 CHECK(yp_create(&d, 0, &e) == YP_OK);
                 const int nw = yp_weight_count(e);
@@ -72,7 +75,7 @@ int main() {
                 CHECK(yp_forward(e, nullptr, 1, 64, 64, nullptr, nullptr, nullptr, nullptr) < 0);
                 CHECK(yp_destroy(e) == YP_OK);
             }
-    yp_model_desc bad{'q', 80, 0, 0, 300};
+    yp_model_desc bad{'q', 80, 0, 0, 300, 0};
     yp_engine* e = nullptr;
     CHECK(yp_create(&bad, 0, &e) < 0);
     printf("asan_host: ok (%ld scheduled launches walked)\n", launches);

@@ -84,6 +84,7 @@ struct Op {
     int scd_pre = -1;             // OP_DWCONV 3x3 s2 closing an SCDown: index of the 1x1 conv in front of it
     bool fused5 = false;          // plan decision: that 1x1 and this depthwise conv run as scdown_fused_kernel
     int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
+    bool nms = false;             // OP_HEAD: conf filter + class-aware NMS (YOLOv8 / YOLO11) instead of the two-stage top-k (v10)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -197,7 +198,12 @@ struct HeadParams {
     void* scratch;                            // device scratch, head_scratch_bytes(B, A)
     const unsigned* mk[3];                    // per-level anchor-max keys [B][HW_l] (bits of sigmoid(max_c logit)); when set, the
                                               // class-max pass already ran (OP_AMAX) and `scratch` is not used
+    // NMS heads (YOLOv8 / YOLO11, head_nms.hip): device parameters [conf, iou] and per-image candidate scratch [B][A][8] floats
+    const float* nms_params;
+    float* nms_ws;
 };
+hipError_t launch_head_nms(const HeadParams& p, hipStream_t st);
+size_t head_nms_scratch_bytes(int B, int A);
 
 // Four SiLUs with the two multiplies and the add as packed fp32 operations (v_pk_mul_f32 / v_pk_add_f32: two values per
 // instruction). Same operations and roundings as  x * rcp(1 + exp2(-x * log2e))  element by element, so the same bits; the

@@ -79,6 +79,10 @@ struct yp_engine {
     // call to call in ordinary use, and every change would mean capture + instantiate + destroy); yp_forward copies the
     // ~0.3 MB out behind the replay
     float* o_det = nullptr; int32_t* o_idx = nullptr; float* o_coeff = nullptr; size_t o_cap = 0;
+    // NMS heads (families v8 / 11)
+    float nms_conf = 0.25f, nms_iou = 0.7f;
+    float* d_nms = nullptr;               // device copy of [conf, iou]
+    void* nms_ws = nullptr; size_t nms_ws_bytes = 0;
     int es() const { return dtype == DT_BF16 ? 2 : 4; }
 };
 
@@ -177,6 +181,60 @@ struct Builder {
         conv(p + ".cv2", full(Y), out, 1, 1, ACT_SILU);
         if (m1 >= 0) { e.ops.back().c2f_m1 = m1; e.ops.back().c2f_m2 = m1 + 1; }    // (t and the c slice have no other reader)
     }
+    // plain Bottleneck with hidden width ch (C3k2's default e = 0.5; C3k's inner ones e = 1.0)
+    void bottleneck(const std::string& q, View x, View y, int ch, bool shortcut) {
+        const int t = tensor(q + ".cv1", ch, sdiv_of(x));
+        conv(q + ".cv1", x, full(t), 3, 1, ACT_SILU);
+        conv(q + ".cv2", full(t), y, 3, 1, ACT_SILU, shortcut ? x : View{});
+    }
+    // C3k2 (ultralytics block.py, YOLO11): C2f whose inner modules are Bottleneck(c, c, e = 0.5) or C3k(c, c, 2)
+    void c3k2(const std::string& p, View in, View out, int c2, int n, bool c3k, double e) {
+        const int c = (int)(c2 * e), sd = sdiv_of(in);
+        const int Y = tensor(p + ".cat", (2 + n) * c, sd);
+        conv(p + ".cv1", in, View{Y, 0, 2 * c}, 1, 1, ACT_SILU);
+        for (int j = 0; j < n; ++j) {
+            const View x{Y, (1 + j) * c, c}, y{Y, (2 + j) * c, c};
+            const std::string q = p + ".m." + std::to_string(j);
+            const int c_ = c / 2;
+            if (!c3k) { bottleneck(q, x, y, c_, true); continue; }
+            // C3k: cv3(cat(m(cv1(x)), cv2(x))), m = two Bottleneck(c_, c_, k = 3, e = 1.0)
+            const int Z = tensor(q + ".cat", 2 * c_, sd);
+            const int a0 = tensor(q + ".cv1", c_, sd), a1 = tensor(q + ".m.0", c_, sd);
+            conv(q + ".cv1", x, full(a0), 1, 1, ACT_SILU);
+            bottleneck(q + ".m.0", full(a0), full(a1), c_, true);
+            bottleneck(q + ".m.1", full(a1), View{Z, 0, c_}, c_, true);
+            conv(q + ".cv2", x, View{Z, c_, c_}, 1, 1, ACT_SILU);
+            conv(q + ".cv3", full(Z), y, 1, 1, ACT_SILU);
+        }
+        conv(p + ".cv2", full(Y), out, 1, 1, ACT_SILU);
+    }
+    // C2PSA (YOLO11): cv1 -> split(a, b) -> n x PSABlock on b -> cv2(cat(a, b))
+    void c2psa(const std::string& p, View in, View out, int n) {
+        const int c = in.C / 2, sd = sdiv_of(in);
+        const int nh = c / 64, hd = c / nh, kd = hd / 2;
+        const int P = tensor(p + ".cv1", 2 * c, sd);
+        conv(p + ".cv1", in, full(P), 1, 1, ACT_SILU);
+        const View b{P, c, c};
+        for (int j = 0; j < n; ++j) {
+            const std::string q = p + ".m." + std::to_string(j);
+            const int Q = tensor(q + ".attn.qkv", c + 2 * kd * nh, sd);
+            conv(q + ".attn.qkv", b, full(Q), 1, 1, ACT_NONE);
+            const int O = tensor(q + ".attn.o", c, sd);
+            {
+                Op o;
+                o.kind = OP_ATTN; o.name = q + ".attn.o"; o.in = full(Q); o.out = full(O); o.nh = nh; o.kd = kd; o.hd = hd;
+                e.ops.push_back(o);
+            }
+            const int Yp = tensor(q + ".attn.pe", c, sd);
+            dwconv(q + ".attn.pe", View{Q, 2 * kd, c}, full(Yp), 3, 1, ACT_NONE, full(O), hd, 2 * kd + hd);
+            const int B1 = tensor(q + ".attn.proj", c, sd);
+            conv(q + ".attn.proj", full(Yp), full(B1), 1, 1, ACT_NONE, b);
+            const int Fh = tensor(q + ".ffn.0", 2 * c, sd);
+            conv(q + ".ffn.0", full(B1), full(Fh), 1, 1, ACT_SILU);
+            conv(q + ".ffn.1", full(Fh), b, 1, 1, ACT_NONE, full(B1));
+        }
+        conv(p + ".cv2", full(P), out, 1, 1, ACT_SILU);
+    }
     void scdown(const std::string& p, View in, View out) {
         const int t = tensor(p + ".cv1", out.C, sdiv_of(in));
         conv(p + ".cv1", in, full(t), 1, 1, ACT_SILU);
@@ -227,7 +285,157 @@ struct Builder {
     }
 };
 
+static int finish_graph_passes(yp_engine& e);
+
+// YOLOv8-seg / YOLO11-seg (ultralytics cfg/models/v8/yolov8-seg.yaml, cfg/models/11/yolo11-seg.yaml [U]; the checkpoints of
+// reference yolo_seg/app.py:218-223 and yolo_seg/yolo_with_deva.py:226): backbone + PAN neck + Segment head (box / class /
+// mask-coefficient branches per level, Proto on P3), post-process = conf filter + NMS (OP_HEAD with nms)
+static int build_graph_seg(yp_engine& e) {
+    const int fam = e.desc.family, v = e.desc.variant;
+    Scale sc;
+    if (fam == YP_FAMILY_V8) {
+        switch (v) { case 'n': sc = {0.33, 0.25, 1024}; break; case 's': sc = {0.33, 0.50, 1024}; break; case 'm': sc = {0.67, 0.75, 768}; break;
+                     case 'l': sc = {1.00, 1.00, 512}; break; case 'x': sc = {1.00, 1.25, 512}; break; default: return fail(YP_ERR_ARG, "unknown variant '%c'", v); }
+    } else {
+        switch (v) { case 'n': sc = {0.50, 0.25, 1024}; break; case 's': sc = {0.50, 0.50, 1024}; break; case 'm': sc = {0.50, 1.00, 512}; break;
+                     case 'l': sc = {1.00, 1.00, 512}; break; case 'x': sc = {1.00, 1.50, 512}; break; default: return fail(YP_ERR_ARG, "unknown variant '%c'", v); }
+    }
+    if (e.desc.task != YP_TASK_SEGMENT) return fail(YP_ERR_ARG, "the v8 / 11 families are segmentation models here (task must be YP_TASK_SEGMENT)");
+    Builder B(e);
+    auto C = [&](int c) { return make_div8(std::min(c, sc.maxc) * sc.width); };
+    auto N = [&](int n) { return n > 1 ? std::max(py_round(n * sc.depth), 1) : n; };
+    const bool v8 = fam == YP_FAMILY_V8;
+    const bool big = !v8 && (v == 'm' || v == 'l' || v == 'x');       // parse_model: C3k2 gets c3k = True for scales m, l, x
+    const int c0 = C(64), c1 = C(128), c2 = C(v8 ? 128 : 256), c3 = C(256), c4 = C(v8 ? 256 : 512), c5 = C(512), c6 = C(512), c7 = C(1024),
+              c8 = C(1024), c9 = C(1024), c10 = C(1024), cn4 = C(512), cn3 = C(256), cd3 = C(256), cn4b = C(512), cd4 = C(512), cn5 = C(1024);
+    const int ctop = v8 ? c9 : c10;                                      // what the neck starts from (SPPF output / C2PSA output)
+    const int idx0 = v8 ? 10 : 11;                                       // layer index of the first Upsample
+    auto L = [&](int i) { return "model." + std::to_string(i); };
+    // concat buffers of the neck, producers write straight into their slice
+    const int Ta = B.tensor(L(idx0 + 1), ctop + c6, 16);                // [up(top), L6]
+    const int Tb = B.tensor(L(idx0 + 4), cn4 + c4, 8);                  // [up(n4), L4]
+    const int Tc = B.tensor(L(idx0 + 7), cd3 + cn4, 16);                // [down(P3), n4]
+    const int Td = B.tensor(L(idx0 + 10), cd4 + ctop, 32);              // [down(P4), top]
+    const View o4{Tb, cn4, c4}, o6{Ta, ctop, c6}, on4{Tc, cd3, cn4}, otop{Td, cd4, ctop};
+    auto block = [&](int i, View in, View out, int cc, int reps, bool shortcut, bool c3k, double ee) {
+        if (v8) B.c2f(L(i), in, out, cc, N(reps), shortcut, false, false);
+        else B.c3k2(L(i), in, out, cc, N(reps), c3k, ee);
+    };
+    const int t0 = B.tensor(L(0), c0, 2);
+    {
+        Op o;
+        o.kind = OP_STEM; o.name = L(0); o.out = B.full(t0); o.k = 3; o.s = 2; o.act = ACT_SILU;
+        o.widx = B.weight(L(0), c0, 3, 3, 1, false, true);
+        e.ops.push_back(o);
+    }
+    const int t1 = B.tensor(L(1), c1, 4);
+    B.conv(L(1), B.full(t0), B.full(t1), 3, 2, ACT_SILU);
+    const int t2 = B.tensor(L(2), c2, 4);
+    block(2, B.full(t1), B.full(t2), c2, v8 ? 3 : 2, true, big, 0.25);
+    const int t3 = B.tensor(L(3), c3, 8);
+    B.conv(L(3), B.full(t2), B.full(t3), 3, 2, ACT_SILU);
+    block(4, B.full(t3), o4, c4, v8 ? 6 : 2, true, big, 0.25);
+    const int t5 = B.tensor(L(5), c5, 16);
+    B.conv(L(5), o4, B.full(t5), 3, 2, ACT_SILU);
+    block(6, B.full(t5), o6, c6, v8 ? 6 : 2, true, true, 0.5);
+    const int t7 = B.tensor(L(7), c7, 32);
+    B.conv(L(7), o6, B.full(t7), 3, 2, ACT_SILU);
+    const int t8 = B.tensor(L(8), c8, 32);
+    block(8, B.full(t7), B.full(t8), c8, v8 ? 3 : 2, true, true, 0.5);
+    if (v8) B.sppf(L(9), B.full(t8), otop);
+    else {
+        const int t9 = B.tensor(L(9), c9, 32);
+        B.sppf(L(9), B.full(t8), B.full(t9));
+        B.c2psa(L(10), B.full(t9), otop, N(2));
+    }
+    B.upsample(L(idx0), otop, View{Ta, 0, ctop});
+    block(idx0 + 2, B.full(Ta), on4, cn4, v8 ? 3 : 2, false, big, 0.5);
+    B.upsample(L(idx0 + 3), on4, View{Tb, 0, cn4});
+    const int tp3 = B.tensor(L(idx0 + 5), cn3, 8);
+    block(idx0 + 5, B.full(Tb), B.full(tp3), cn3, v8 ? 3 : 2, false, big, 0.5);
+    B.conv(L(idx0 + 6), B.full(tp3), View{Tc, 0, cd3}, 3, 2, ACT_SILU);
+    const int tp4 = B.tensor(L(idx0 + 8), cn4b, 16);
+    block(idx0 + 8, B.full(Tc), B.full(tp4), cn4b, v8 ? 3 : 2, false, big, 0.5);
+    B.conv(L(idx0 + 9), B.full(tp4), View{Td, 0, cd4}, 3, 2, ACT_SILU);
+    const int tp5 = B.tensor(L(idx0 + 11), cn5, 32);
+    block(idx0 + 11, B.full(Td), B.full(tp5), cn5, v8 ? 3 : 2, false, true, 0.5);
+    // (C2f shortcut of the v8 neck is False; C3k2 keeps its default shortcut = True everywhere: the yaml passes only c3k)
+
+    // ---- Segment head -----------------------------------------------------------------------------------------------------
+    const int nc = e.desc.nc;
+    const std::string H = L(idx0 + 12);
+    const View feat[3] = {B.full(tp3), B.full(tp4), B.full(tp5)};
+    const int hc2 = std::max(std::max(16, feat[0].C / 4), 64);
+    const int hc3 = std::max(feat[0].C, std::min(nc, 100));
+    const int hc4 = std::max(feat[0].C / 4, YP_NM);
+    const int npr = make_div8(std::min(256, sc.maxc) * sc.width);
+    Op head;
+    head.kind = OP_HEAD; head.name = H + ".postprocess"; head.nlev = 3; head.nms = true;
+    for (int l = 0; l < 3; ++l) {
+        const std::string Ls = std::to_string(l);
+        const int sd = 8 << l;
+        const View x = feat[l];
+        const std::string pb = H + ".cv2." + Ls, pc = H + ".cv3." + Ls, pm = H + ".cv4." + Ls;
+        const int b0 = B.tensor(pb + ".0", hc2, sd), b1 = B.tensor(pb + ".1", hc2, sd), b2 = B.tensor(pb + ".2", 64, sd, true);
+        B.lane = 1 + 3 * l;
+        B.conv(pb + ".0", x, B.full(b0), 3, 1, ACT_SILU);
+        B.conv(pb + ".1", B.full(b0), B.full(b1), 3, 1, ACT_SILU);
+        B.conv(pb + ".2", B.full(b1), B.full(b2), 1, 1, ACT_NONE);
+        B.lane = 2 + 3 * l;
+        const int k4 = B.tensor(pc + ".2", nc, sd, true);
+        if (v8) {                                                       // legacy Detect: dense 3x3 -> 3x3 -> 1x1
+            const int k0 = B.tensor(pc + ".0", hc3, sd), k1 = B.tensor(pc + ".1", hc3, sd);
+            B.conv(pc + ".0", x, B.full(k0), 3, 1, ACT_SILU);
+            B.conv(pc + ".1", B.full(k0), B.full(k1), 3, 1, ACT_SILU);
+            B.conv(pc + ".2", B.full(k1), B.full(k4), 1, 1, ACT_NONE);
+        } else {
+            const int k0 = B.tensor(pc + ".0.0", x.C, sd), k1 = B.tensor(pc + ".0.1", hc3, sd), k2 = B.tensor(pc + ".1.0", hc3, sd), k3 = B.tensor(pc + ".1.1", hc3, sd);
+            B.dwconv(pc + ".0.0", x, B.full(k0), 3, 1, ACT_SILU);
+            B.conv(pc + ".0.1", B.full(k0), B.full(k1), 1, 1, ACT_SILU);
+            B.dwconv(pc + ".1.0", B.full(k1), B.full(k2), 3, 1, ACT_SILU);
+            B.conv(pc + ".1.1", B.full(k2), B.full(k3), 1, 1, ACT_SILU);
+            B.conv(pc + ".2", B.full(k3), B.full(k4), 1, 1, ACT_NONE);
+        }
+        {
+            const int am = B.tensor(H + ".amax." + Ls, 1, sd, true);
+            Op o;
+            o.lane = B.lane;
+            o.kind = OP_AMAX; o.name = H + ".amax." + Ls; o.in = B.full(k4); o.out = B.full(am);
+            e.ops.push_back(o);
+            head.amax[l] = B.full(am);
+        }
+        const int m0 = B.tensor(pm + ".0", hc4, sd), m1 = B.tensor(pm + ".1", hc4, sd), m2 = B.tensor(pm + ".2", YP_NM, sd, true);
+        B.lane = 3 + 3 * l;
+        B.conv(pm + ".0", x, B.full(m0), 3, 1, ACT_SILU);
+        B.conv(pm + ".1", B.full(m0), B.full(m1), 3, 1, ACT_SILU);
+        B.conv(pm + ".2", B.full(m1), B.full(m2), 1, 1, ACT_NONE);
+        head.box[l] = B.full(b2); head.cls[l] = B.full(k4); head.cf[l] = B.full(m2);
+    }
+    {
+        const std::string pp = H + ".proto";
+        const int p0 = B.tensor(pp + ".cv1", npr, 8), p1 = B.tensor(pp + ".upsample", npr, 4), p2 = B.tensor(pp + ".cv2", npr, 4), p3 = B.tensor(pp + ".cv3", YP_NM, 4);
+        B.lane = 10;
+        B.conv(pp + ".cv1", feat[0], B.full(p0), 3, 1, ACT_SILU);
+        {
+            Op o;
+            o.lane = B.lane;
+            o.kind = OP_CONVT; o.name = pp + ".upsample"; o.in = B.full(p0); o.out = B.full(p1); o.k = 2; o.s = 2; o.act = ACT_NONE;
+            o.widx = B.weight(pp + ".upsample", npr, npr, 2, 1, true);
+            e.ops.push_back(o);
+        }
+        B.conv(pp + ".cv2", B.full(p1), B.full(p2), 3, 1, ACT_SILU);
+        B.conv(pp + ".cv3", B.full(p2), B.full(p3), 1, 1, ACT_SILU);
+        e.proto_t = p3;
+    }
+    B.lane = 0;
+    head.lane = 0;
+    e.ops.push_back(head);
+    return finish_graph_passes(e);
+}
+
 static int build_graph(yp_engine& e) {
+    if (e.desc.family == YP_FAMILY_V8 || e.desc.family == YP_FAMILY_11) return build_graph_seg(e);
+    if (e.desc.family != YP_FAMILY_V10) return fail(YP_ERR_ARG, "unknown model family %d", e.desc.family);
     Scale sc;
     if (!variant_scale(e.desc.variant, sc)) return fail(YP_ERR_ARG, "unknown variant '%c'", e.desc.variant);
     const int v = e.desc.variant;
@@ -356,6 +564,11 @@ static int build_graph(yp_engine& e) {
     B.lane = 0;
     head.lane = 0;
     e.ops.push_back(head);
+    return finish_graph_passes(e);
+}
+
+// graph passes shared by every family: they only look at op kinds, shapes and who reads what
+static int finish_graph_passes(yp_engine& e) {
     // ---- fusion pass: depthwise 3x3 (s1, SiLU) whose only consumer is the next op, a 1x1 conv ------------------------------
     for (size_t i = 0; i + 1 < e.ops.size(); ++i) {
         const Op& d = e.ops[i];
@@ -529,7 +742,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
             else snprintf(buf, sizeof(buf), "stem_kernel<f32>");
             o.kernel = buf;
         } else if (o.kind == OP_POOL3 && e.dtype == DT_BF16 && (o.in.C & 31) == 0) o.kernel = "sppf_pool3_bf16_kernel";
-        else o.kernel = kn[o.kind];
+        else o.kernel = (o.kind == OP_HEAD && o.nms) ? "head_nms_kernel" : kn[o.kind];
     }
     // algorithmic work of the graph as it runs: an op whose work moved into a fused consumer reports nothing and launches
     // nothing; the consumer reports the FLOPs of all its stages and the bytes of what it reads and writes (the intermediates
@@ -588,6 +801,22 @@ static int allocate_plan(yp_engine& e) {
             e.head_ws = nullptr;
             HIPCHK(hipMalloc(&e.head_ws, need));
             e.head_ws_bytes = need;
+        }
+    }
+    if (e.desc.family != YP_FAMILY_V10) {
+        size_t A = 0;
+        for (int l = 0; l < 3; ++l) A += (size_t)(e.pH / (8 << l)) * (e.pW / (8 << l));
+        const size_t need = head_nms_scratch_bytes(e.pB, (int)A);
+        if (need > e.nms_ws_bytes) {
+            if (e.nms_ws) HIPCHK(hipFree(e.nms_ws));
+            e.nms_ws = nullptr; e.nms_ws_bytes = 0;
+            HIPCHK(hipMalloc(&e.nms_ws, need));
+            e.nms_ws_bytes = need;
+        }
+        if (!e.d_nms) {
+            HIPCHK(hipMalloc((void**)&e.d_nms, 2 * sizeof(float)));
+            const float v[2] = {e.nms_conf, e.nms_iou};
+            HIPCHK(hipMemcpy(e.d_nms, v, sizeof(v), hipMemcpyHostToDevice));
         }
     }
     if ((size_t)e.pB > e.o_cap) {
@@ -786,6 +1015,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             p.B = B; p.nc = e.desc.nc; p.max_det = e.desc.max_det;
             p.det = a.det; p.idx = a.idx; p.coeff = (o.cf[0].t >= 0) ? a.coeff : nullptr; p.scratch = e.head_ws;
             for (int l = 0; l < 3; ++l) p.mk[l] = (o.amax[l].t >= 0) ? (const unsigned*)T(o.amax[l]).ptr : nullptr;
+            if (o.nms) { p.nms_params = e.d_nms; p.nms_ws = (float*)e.nms_ws; return launch_head_nms(p, st); }
             return launch_head(p, st);
         }
     }
@@ -1270,6 +1500,8 @@ int yp_destroy(yp_engine* e) {
     if (e->arena) (void)hipFree(e->arena);
     if (e->mask_ws) (void)hipFree(e->mask_ws);
     if (e->head_ws) (void)hipFree(e->head_ws);
+    if (e->nms_ws) (void)hipFree(e->nms_ws);
+    if (e->d_nms) (void)hipFree(e->d_nms);
     if (e->o_det) { (void)hipFree(e->o_det); (void)hipFree(e->o_idx); (void)hipFree(e->o_coeff); }
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -1616,6 +1848,21 @@ int yp_debug_host_selftest(yp_engine* e) {
     for (int l = 1; l < e->n_lanes; ++l) used += seen[l];
     if (used != (int)e->lanes_used.size()) return fail(YP_ERR_STATE, "internal: %d side lanes launch but %zu are joined", used, e->lanes_used.size());
     return (int)e->lane_steps.size() + (acc == 0 ? 0 : 0);
+}
+
+int yp_set_nms(yp_engine* e, float conf, float iou) {
+    if (!e) return fail(YP_ERR_ARG, "null engine");
+    if (!(conf >= 0.f && conf < 1.f) || !(iou > 0.f && iou <= 1.f)) return fail(YP_ERR_ARG, "yp_set_nms: conf in [0,1), iou in (0,1]");
+    if (conf == e->nms_conf && iou == e->nms_iou) return YP_OK;
+    e->nms_conf = conf; e->nms_iou = iou;
+    if (e->d_nms) {
+        // a running forward may still read the old pair: order the update behind everything enqueued so far
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipDeviceSynchronize());
+        const float v[2] = {conf, iou};
+        HIPCHK(hipMemcpy(e->d_nms, v, sizeof(v), hipMemcpyHostToDevice));
+    }
+    return YP_OK;
 }
 
 int yp_set_autotune(yp_engine* e, int enable) {

@@ -23,7 +23,7 @@ OP_KINDS = {0: "stem", 1: "conv", 2: "dwconv", 3: "pool5", 4: "upsample", 5: "at
 
 
 class ModelDesc(C.Structure):
-    _fields_ = [("variant", C.c_int), ("nc", C.c_int), ("task", C.c_int), ("dtype", C.c_int), ("max_det", C.c_int)]
+    _fields_ = [("variant", C.c_int), ("nc", C.c_int), ("task", C.c_int), ("dtype", C.c_int), ("max_det", C.c_int), ("family", C.c_int)]
 
 
 class YolopError(RuntimeError):
@@ -67,6 +67,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_profile.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]
     lib.yp_set_graph.argtypes = [vp, C.c_int]
     lib.yp_set_autotune.argtypes = [vp, C.c_int]
+    lib.yp_set_nms.argtypes = [vp, C.c_float, C.c_float]
+    lib.yp_set_nms.restype = C.c_int
     lib.yp_debug_host_selftest.argtypes = [vp]
     lib.yp_debug_host_selftest.restype = C.c_int
     lib.yp_debug_force_conv_cfg.argtypes = [C.c_int]
@@ -93,7 +95,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
+           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy",
            "yp_u2net_create", "yp_u2net_destroy", "yp_u2net_weight_count", "yp_u2net_weight_info", "yp_u2net_set_weight", "yp_u2net_finalize",
            "yp_u2net_forward", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
@@ -152,13 +154,16 @@ class Engine:
 
     def __init__(self, variant: str = "s", nc: int = 80, seg: bool = False, dtype: str = "bf16",
                  device: int = 0, max_det: int = 300, state: Optional[Dict[str, torch.Tensor]] = None,
-                 finalize: bool = True):
+                 finalize: bool = True, family: str = "v10"):
         self.lib = load_library()
         self.variant, self.nc, self.seg, self.max_det = variant, nc, seg, max_det
+        self.family = family
+        if family != "v10" and not seg:
+            raise ValueError("the v8 / 11 families are built as segmentation models (the checkpoints the reference ships)")
         self.dtype = {"bf16": YP_BF16, "fp32": YP_F32, "f32": YP_F32}[dtype]
         self.device_index = int(device)
         self._h = C.c_void_p()
-        desc = ModelDesc(ord(variant), nc, TASK_SEGMENT if seg else TASK_DETECT, self.dtype, max_det)
+        desc = ModelDesc(ord(variant), nc, TASK_SEGMENT if seg else TASK_DETECT, self.dtype, max_det, {"v10": 0, "v8": 8, "11": 11}[family])
         self._chk(self.lib.yp_create(C.byref(desc), self.device_index, C.byref(self._h)))
         self._keep: List[torch.Tensor] = []
         self.finalized = False
@@ -211,6 +216,10 @@ class Engine:
 
     def set_autotune(self, enable: bool) -> None:
         self._chk(self.lib.yp_set_autotune(self._h, 1 if enable else 0))
+
+    def set_nms(self, conf: float = 0.25, iou: float = 0.7) -> None:
+        """families v8 / 11: thresholds of the NMS inside the forward (`.predict(conf=, iou=)`)."""
+        self._chk(self.lib.yp_set_nms(self._h, float(conf), float(iou)))
 
     def set_graph(self, enable: bool) -> None:
         self._chk(self.lib.yp_set_graph(self._h, 1 if enable else 0))

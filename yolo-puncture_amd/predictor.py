@@ -229,19 +229,32 @@ class YOLO:
                  device: Optional[Union[int, str, torch.device]] = None, nc: int = 80, seed: int = 0):
         self.ckpt_path = str(model)
         self.dtype = dtype
+        self.family = "v10"
         if self.ckpt_path.startswith("synthetic:"):
-            spec = self.ckpt_path.split(":", 1)[1]
-            self.variant, self.seg = spec.split("-")[0], spec.endswith("-seg")
+            spec = self.ckpt_path.split(":", 1)[1]              # "s", "s-seg" (YOLOv10) ; "v8n-seg", "11x-seg" (the app's families)
+            base = spec.split("-")[0]
+            self.seg = spec.endswith("-seg")
             self.nc = nc
-            self._state = synthetic_state(self.variant, nc, self.seg, seed=seed)
+            if base[:2] in ("v8", "11"):
+                from .weights import synthetic_state_family
+                self.family, self.variant = base[:2], base[2:]
+                if not self.seg:
+                    raise ValueError("the v8 / 11 families are built as segmentation models")
+                self._state = synthetic_state_family(self.family, self.variant, nc, seed=seed)
+            else:
+                self.variant = base
+                self._state = synthetic_state(self.variant, nc, self.seg, seed=seed)
             self.names = {i: str(i) for i in range(nc)}
         else:
             if not os.path.isfile(self.ckpt_path):
                 raise FileNotFoundError(f"{self.ckpt_path}: no such checkpoint (nothing is downloaded)")
             st, meta = read_ultralytics_pt(self.ckpt_path)
-            if meta.get("variant") is None or meta.get("nc") is None:
-                raise ValueError(f"{self.ckpt_path}: not a YOLOv10 checkpoint this engine understands "
-                                 "(v8/11 trunks are not built yet)")
+            if meta.get("family") is None or meta.get("variant") is None or meta.get("nc") is None:
+                raise ValueError(f"{self.ckpt_path}: not a checkpoint this engine understands (YOLOv10 detect / v10-seg, "
+                                 "YOLOv8-seg, YOLO11-seg)")
+            if meta["family"] != "v10" and not meta["seg"]:
+                raise ValueError(f"{self.ckpt_path}: YOLOv8 / YOLO11 detect-only checkpoints are not built; the reference uses the -seg models")
+            self.family = meta["family"]
             self.variant, self.seg, self.nc = meta["variant"], bool(meta["seg"]), int(meta["nc"])
             self._state = st
             names = meta.get("names")
@@ -273,10 +286,10 @@ class YOLO:
             mt = os.path.getmtime(self.ckpt_path)
         except OSError:
             mt = 0.0
-        key = (self.ckpt_path, mt, self.variant, self.nc, self.seg, self.dtype, self._dev_index)
+        key = (self.ckpt_path, mt, self.family, self.variant, self.nc, self.seg, self.dtype, self._dev_index)
         eng = _ENGINE_CACHE.get(key)
         if eng is None:
-            eng = Engine(self.variant, self.nc, self.seg, self.dtype, self._dev_index, state=self._state)
+            eng = Engine(self.variant, self.nc, self.seg, self.dtype, self._dev_index, state=self._state, family=self.family)
             # the reference's real workload is one frame per call (yolo_seg/app.py:85-91): ~90 eager launches per frame would be
             # launch-bound, so the forward is replayed as one hipGraph per input shape (the engine runs every new shape once eagerly
             # before it captures; the graph is keyed on the input pointer, hence the persistent batch buffers below)
@@ -289,13 +302,15 @@ class YOLO:
         return self.predict(source, **kw)
 
     def predict(self, source=None, conf: float = 0.25, retina_masks: bool = False, device=None, imgsz: int = 640,
-                max_det: int = 300, stream: bool = False, verbose: bool = False, **ignored) -> List[Results]:
+                max_det: int = 300, stream: bool = False, verbose: bool = False, iou: float = 0.7, **ignored) -> List[Results]:
         if source is None:
             raise ValueError("predict() needs a source (ndarray BGR HWC uint8, PIL.Image, path or a list of them)")
         if device is not None:
             self._set_device(device)
         imgs, paths = hostops.load_sources(source)                    # list of BGR uint8 HWC (ndarray => taken as BGR)
         eng = self._engine()
+        if self.family != "v10":
+            eng.set_nms(conf, iou)                                    # v8 / 11: conf filter + NMS run inside the forward
         dev = torch.device("cuda", self._dev_index)
         results: List[Results] = []
         # frames that letterbox to the same shape run as one batch
@@ -371,6 +386,8 @@ class YOLO:
         if batch is None:
             batch = bcache[(self._dev_index, 1, H, W)] = torch.empty((1, H, W, 3), dtype=torch.uint8, device=dev)
         letterbox_device(raw, geo, out=batch[0])
+        if self.family != "v10":
+            eng.set_nms(conf, 0.7)
         out = eng.forward(batch)
         d = out["det"][0]
         keep = d[:, 4] > conf

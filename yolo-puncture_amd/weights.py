@@ -98,11 +98,43 @@ def read_ultralytics_pt(path: str) -> Tuple[Dict[str, torch.Tensor], dict]:
         meta["yaml"] = getattr(mod, "yaml", None)
         meta["names"] = getattr(mod, "names", None)
     state = {k: v.float() for k, v in state.items() if v.is_floating_point()}
-    meta["variant"] = guess_variant(state)
+    meta["family"] = guess_family(state)
     meta["seg"] = any(".proto." in k for k in state)
-    nck = [k for k in state if k.endswith("one2one_cv3.0.2.weight")]
+    if meta["family"] == "v10":
+        meta["variant"] = guess_variant(state)
+        nck = [k for k in state if k.endswith("one2one_cv3.0.2.weight")]
+    else:
+        meta["variant"] = guess_variant_family(state, meta["family"]) if meta["family"] else None
+        hi = {"v8": 22, "11": 23}.get(meta["family"], -1)
+        nck = [k for k in state if k == f"model.{hi}.cv3.0.2.weight"]
     meta["nc"] = int(state[nck[0]].shape[0]) if nck else None
     return state, meta
+
+
+def guess_family(state: Dict[str, torch.Tensor]) -> Optional[str]:
+    """Which ultralytics yaml a checkpoint follows: 'v10' (one-to-one head), '11' (C3k2 / C2PSA, head at model.23) or 'v8' (C2f,
+    head at model.22) - the latter two are what the reference's UI offers (yolo_seg/app.py:218-223)."""
+    if any(".one2one_cv2." in k for k in state):
+        return "v10"
+    if "model.23.cv2.0.0.conv.weight" in state and any(k.startswith("model.10.m.0.attn.") for k in state):
+        return "11"
+    if "model.22.cv2.0.0.conv.weight" in state and "model.9.cv2.conv.weight" in state:
+        return "v8"
+    return None
+
+
+_STEM = {"v8": {"n": 16, "s": 32, "m": 48, "l": 64, "x": 80}, "11": {"n": 16, "s": 32, "m": 64, "l": 64, "x": 96}}
+
+
+def guess_variant_family(state: Dict[str, torch.Tensor], family: str) -> Optional[str]:
+    if "model.0.conv.weight" not in state:
+        return None
+    c0 = int(state["model.0.conv.weight"].shape[0])
+    cands = [v for v, c in _STEM[family].items() if c == c0]
+    if len(cands) > 1:                       # yolo11 m / l share the widths, l repeats every block twice
+        n2 = len({k.split(".")[3] for k in state if k.startswith("model.2.m.")})
+        cands = [v for v in cands if (2 if v in "lx" else 1) == n2] or cands
+    return cands[0] if cands else None
 
 
 def guess_variant(state: Dict[str, torch.Tensor]) -> Optional[str]:
@@ -144,9 +176,10 @@ def fold_state(state: Dict[str, torch.Tensor]) -> Dict[str, Tuple[torch.Tensor, 
             w7, b7 = out.pop(n[:-1])
             w3, b3 = out.pop(n)
             out[n[: -len(".conv1")]] = (w7 + torch.nn.functional.pad(w3, [2, 2, 2, 2]), b7 + b3)
-    for n in list(out):
-        if n.startswith("model.23.cv2.") or n.startswith("model.23.cv3."):
-            del out[n]                      # one-to-many twins never reach the result (README.md:25)
+    if any(".one2one_cv2." in n for n in out):
+        for n in list(out):
+            if n.startswith("model.23.cv2.") or n.startswith("model.23.cv3."):
+                del out[n]                  # v10: one-to-many twins never reach the result (README.md:25)
     return out
 
 
@@ -241,6 +274,50 @@ def synthetic_state(variant: str = "s", nc: int = 80, seg: bool = False, seed: i
                   (torch.rand(npr, generator=_gen(p + ".proto.up.b", seed)) - 0.5) * 0.2, transpose=True)
         conv_bn(f"{p}.proto.cv2", npr, npr, 3)
         conv_bn(f"{p}.proto.cv3", npr, NM, 1)
+    return st
+
+
+def synthetic_state_family(family: str, variant: str = "n", nc: int = 80, seed: int = 0, cls_bias: Optional[float] = None,
+                           gain: float = 1.0, head_gain: float = 1.0) -> Dict[str, torch.Tensor]:
+    """Seeded unfused state dict of a YOLOv8-seg / YOLO11-seg checkpoint. The names and shapes come from the engine's own graph
+    (yp_weight_info: no second copy of the layer arithmetic on the host); plain biased convs (the last conv of every head branch,
+    Proto's ConvTranspose) stay plain, everything else becomes conv + BatchNorm as ultralytics stores it."""
+    from .engine import Engine
+    hi = {"v8": 22, "11": 23}[family]
+    eng = Engine(variant, nc, True, "bf16", 0, family=family)
+    table = eng.expected_weights()
+    eng.close()
+    st: Dict[str, torch.Tensor] = {}
+    for name, shape in table:
+        if not name.endswith(".weight"):
+            continue
+        p = name[:-7]
+        plain = p.endswith(".2") and p.startswith(f"model.{hi}.cv") or p.endswith(".proto.upsample")
+        if plain:
+            transpose = p.endswith(".upsample")
+            cin = shape[0] if transpose else shape[1]
+            fan_in = cin * shape[2] * shape[3]
+            st[f"{p}.weight"] = torch.randn(shape, generator=_gen(p + ".w", seed)) * (head_gain * math.sqrt(1.0 / fan_in))
+            cout = shape[1] if transpose else shape[0]
+            if f".cv2." in p:
+                b = torch.full((cout,), 1.0)
+            elif f".cv3." in p:
+                l = int(p.split(".")[3])
+                b = torch.full((cout,), math.log(5 / nc / (640 / (8 << l)) ** 2) if cls_bias is None else cls_bias)
+            elif p.endswith(".upsample"):
+                b = (torch.rand(cout, generator=_gen(p + ".b", seed)) - 0.5) * 0.2
+            else:
+                b = torch.zeros(cout)
+            st[f"{p}.bias"] = b
+        else:
+            c2, c1g, k, _ = shape
+            fan_in = c1g * k * k
+            st[f"{p}.conv.weight"] = torch.randn(shape, generator=_gen(p + ".w", seed)) * (gain * math.sqrt(2.0 / fan_in))
+            st[f"{p}.bn.weight"] = torch.ones(c2)
+            st[f"{p}.bn.bias"] = (torch.rand(c2, generator=_gen(p + ".b", seed)) - 0.5) * 0.2
+            st[f"{p}.bn.running_mean"] = torch.zeros(c2)
+            st[f"{p}.bn.running_var"] = torch.ones(c2)
+    st[f"model.{hi}.dfl.conv.weight"] = torch.arange(REG_MAX, dtype=torch.float32).view(1, REG_MAX, 1, 1)
     return st
 
 
