@@ -126,9 +126,10 @@ def test_facade_predict_and_pt_roundtrip(family, tmp_path):
     family / variant / nc detected from the state dict, boxes + masks against the oracle pipeline."""
     from yolo_puncture_amd import YOLO
     from yolo_puncture_amd.weights import read_ultralytics_pt, save_as_ultralytics_pt
-    frame = rand_image((1, 360, 640, 3), seed=7)[0].numpy()
+    st, ims = make_case_family(family, "n", 80, 0, (1, 384, 640))     # calibrated on this very frame (384x640 letterboxes to itself)
+    frame = ims[0].numpy()
     boxed, _ = po.letterbox(frame)
-    st, _ = make_case_family(family, "n", 80, 0, (2, 96, 128))
+    assert boxed.shape == frame.shape and np.array_equal(boxed, frame)
     path = str(tmp_path / f"{family}n-seg.pt")
     save_as_ultralytics_pt(st, path)
     st_rt, meta = read_ultralytics_pt(path)

@@ -32,13 +32,12 @@ __global__ __launch_bounds__(NT) void head_nms_kernel(const HeadParams p) {
     __shared__ unsigned s_n;
     __shared__ unsigned s_dead[NCAP / 32];
     __shared__ int s_kept[NMAXK];
-    __shared__ int s_nk;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int A = p.A;
     const NmsLocate locate{p.hw[0][0] * p.hw[0][1], p.hw[1][0] * p.hw[1][1], p.hw[2][0] * p.hw[2][1]};
     const float conf = p.nms_params[0], iou_thr = p.nms_params[1];
     const unsigned conf_bits = __float_as_uint(fmaxf(conf, 0.f));
-    if (tid == 0) { s_n = 0; s_nk = 0; }
+    if (tid == 0) s_n = 0;
     for (int i = tid; i < NCAP / 32; i += NT) s_dead[i] = 0u;
     __syncthreads();
     // ---- candidates: score > conf (scores are sigmoids, >= 0: bit patterns order like the floats) ------------------------------

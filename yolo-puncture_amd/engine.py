@@ -247,8 +247,10 @@ class Engine:
 
     def proto(self) -> torch.Tensor:
         """Engine-owned prototypes of the last forward as fp32 [B,Hp,Wp,32] (a copy; test/debug helper)."""
-        t = self.find_tensor("model.23.proto.cv3")
-        return self.read_tensor(t)
+        for t in self.tensors():
+            if t["name"].endswith(".proto.cv3"):
+                return self.read_tensor(t["index"])
+        raise KeyError("proto.cv3")
 
     def masks(self, b: int, coeff: torch.Tensor, boxes: torch.Tensor, out_hw: Tuple[int, int], retina: bool = True,
               want_masks: bool = True, want_ids: bool = False, suppress_small: bool = False, min_area: int = 100):
