@@ -1874,6 +1874,7 @@ int yp_set_autotune(yp_engine* e, int enable) {
 
 int yp_set_graph(yp_engine* e, int enable) {
     if (!e) return fail(YP_ERR_ARG, "null engine");
+    if (e->use_graph == (enable != 0) && e->use_lanes == (enable != 2)) return YP_OK;
     e->use_graph = enable != 0;
     e->use_lanes = enable != 2;          // 2 = graph without concurrent lanes (A/B measurements)
     if (e->gexec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }

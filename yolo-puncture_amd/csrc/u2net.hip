@@ -81,6 +81,14 @@ struct yp_u2net {
     void* arena = nullptr;
     size_t arena_bytes = 0;
     float* d_fuse = nullptr;            // [6 weights | bias | min bits | max bits]
+    // hipGraph replay (the crop is launch-bound: ~170 small kernels): the graph reads an engine-owned copy of the frame and writes
+    // engine-owned results, so neither the caller's input nor its output pointers are baked in; both copies ride the same stream
+    bool use_graph = true, warmed = false;
+    hipStream_t own_stream = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    int gB = 0, gH = 0, gW = 0;
+    uint8_t* in_buf = nullptr; float* o_prob = nullptr; float* o_norm = nullptr; uint8_t* o_mask = nullptr; size_t io_cap = 0;
     int es() const { return dtype == DT_BF16 ? 2 : 4; }
 };
 
@@ -371,6 +379,7 @@ __global__ __launch_bounds__(256) void u2_norm_kernel(const float* __restrict__ 
 static int plan_u2(yp_u2net& e, int B, int H, int W) {
     if (B <= 0 || H < 32 || W < 32) return u2fail(YP_ERR_ARG, "input must be [B,H,W,3] with H,W >= 32 (got %d,%d,%d)", B, H, W);
     if (e.pB == B && e.pH == H && e.pW == W && e.arena) return YP_OK;
+    e.warmed = false;
     int lh[6], lw[6];
     lh[0] = H; lw[0] = W;
     for (int l = 1; l < 6; ++l) { lh[l] = (lh[l - 1] + 1) / 2; lw[l] = (lw[l - 1] + 1) / 2; }
@@ -392,6 +401,7 @@ static int plan_u2(yp_u2net& e, int B, int H, int W) {
     size_t off = 0;
     for (auto& t : e.tensors) { t.ptr = (char*)e.arena + off; off += (t.bytes + 255) & ~(size_t)255; }
     e.pB = B; e.pH = H; e.pW = W;
+    if (e.gexec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(e.gexec); e.gexec = nullptr; }
     return YP_OK;
 }
 
@@ -466,6 +476,11 @@ int yp_u2net_destroy(yp_u2net* e) {
     for (auto& w : e->weights) { if (w.d_w) (void)hipFree(w.d_w); if (w.d_b) (void)hipFree(w.d_b); }
     if (e->arena) (void)hipFree(e->arena);
     if (e->d_fuse) (void)hipFree(e->d_fuse);
+    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    if (e->in_buf) { (void)hipFree(e->in_buf); (void)hipFree(e->o_prob); (void)hipFree(e->o_norm); (void)hipFree(e->o_mask); }
+    if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
     return YP_OK;
 }
@@ -535,6 +550,23 @@ int yp_u2net_finalize(yp_u2net* e) {
     return YP_OK;
 }
 
+static int u2_run(yp_u2net* e, const uint8_t* bgr, float* prob, float* norm, uint8_t* mask, hipStream_t st) {
+    for (const U2Op& o : e->ops) {
+        hipError_t err = run_u2_op(*e, o, bgr, st);
+        if (err != hipSuccess) return u2fail(YP_ERR_HIP, "launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
+    }
+    U2Tail t{};
+    for (int k = 0; k < 6; ++k) { const U2Tensor& s = e->tensors[e->side_t[k]]; t.side[k] = (const float*)s.ptr; t.h[k] = s.H; t.w[k] = s.W; }
+    t.B = e->pB; t.H = e->pH; t.W = e->pW; t.fuse = e->d_fuse; t.minmax = (unsigned*)(e->d_fuse + 7); t.prob = prob;
+    U2HIP(hipMemsetD32Async((hipDeviceptr_t)t.minmax, (int)0x7f800000u, 1, st));
+    U2HIP(hipMemsetD32Async((hipDeviceptr_t)(t.minmax + 1), 0, 1, st));
+    const size_t n = (size_t)e->pB * e->pH * e->pW;
+    hipLaunchKernelGGL(u2_tail_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t);
+    if (norm || mask) hipLaunchKernelGGL(u2_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, prob, t.minmax, norm, mask, n);
+    U2HIP(hipGetLastError());
+    return YP_OK;
+}
+
 int yp_u2net_forward(yp_u2net* e, const uint8_t* bgr_dev, int B, int H, int W, float* prob_out, float* norm_out, uint8_t* mask_out, void* stream) {
     if (!e || !bgr_dev || !prob_out) return u2fail(YP_ERR_ARG, "null argument");
     if (!e->finalized) return u2fail(YP_ERR_STATE, "yp_u2net_finalize has not been called");
@@ -542,20 +574,55 @@ int yp_u2net_forward(yp_u2net* e, const uint8_t* bgr_dev, int B, int H, int W, f
     if (rc != YP_OK) return rc;
     U2HIP(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)stream;
-    for (const U2Op& o : e->ops) {
-        hipError_t err = run_u2_op(*e, o, bgr_dev, st);
-        if (err != hipSuccess) return u2fail(YP_ERR_HIP, "launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
+    if (!e->use_graph || !e->warmed) {            // eager; the first pass of every shape always is (nothing is loaded or configured under a capture)
+        rc = u2_run(e, bgr_dev, prob_out, norm_out, mask_out, st);
+        if (rc == YP_OK) e->warmed = true;
+        return rc;
     }
-    U2Tail t{};
-    for (int k = 0; k < 6; ++k) { const U2Tensor& s = e->tensors[e->side_t[k]]; t.side[k] = (const float*)s.ptr; t.h[k] = s.H; t.w[k] = s.W; }
-    t.B = B; t.H = H; t.W = W; t.fuse = e->d_fuse; t.minmax = (unsigned*)(e->d_fuse + 7); t.prob = prob_out;
-    U2HIP(hipMemsetD32Async((hipDeviceptr_t)t.minmax, (int)0x7f800000u, 1, st));
-    U2HIP(hipMemsetD32Async((hipDeviceptr_t)(t.minmax + 1), 0, 1, st));
     const size_t n = (size_t)B * H * W;
-    hipLaunchKernelGGL(u2_tail_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t);
-    if (norm_out || mask_out)
-        hipLaunchKernelGGL(u2_norm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, prob_out, t.minmax, norm_out, mask_out, n);
-    U2HIP(hipGetLastError());
+    if (n > e->io_cap) {
+        U2HIP(hipDeviceSynchronize());
+        if (e->gexec) { (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        if (e->in_buf) { (void)hipFree(e->in_buf); (void)hipFree(e->o_prob); (void)hipFree(e->o_norm); (void)hipFree(e->o_mask); }
+        e->in_buf = nullptr; e->io_cap = 0;
+        U2HIP(hipMalloc((void**)&e->in_buf, n * 3));
+        U2HIP(hipMalloc((void**)&e->o_prob, n * 4));
+        U2HIP(hipMalloc((void**)&e->o_norm, n * 4));
+        U2HIP(hipMalloc((void**)&e->o_mask, n));
+        e->io_cap = n;
+    }
+    if (!e->own_stream) {
+        U2HIP(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+        U2HIP(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+        U2HIP(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    }
+    if (!e->gexec || e->gB != B || e->gH != H || e->gW != W) {
+        if (e->gexec) { U2HIP(hipStreamSynchronize(e->own_stream)); (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+        hipGraph_t g = nullptr;
+        U2HIP(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
+        rc = u2_run(e, e->in_buf, e->o_prob, e->o_norm, e->o_mask, e->own_stream);
+        const hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
+        if (rc != YP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+        if (ce != hipSuccess) return u2fail(YP_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        U2HIP(hipGraphInstantiate(&e->gexec, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        e->gB = B; e->gH = H; e->gW = W;
+    }
+    U2HIP(hipEventRecord(e->ev_in, st));
+    U2HIP(hipStreamWaitEvent(e->own_stream, e->ev_in, 0));
+    U2HIP(hipMemcpyAsync(e->in_buf, bgr_dev, n * 3, hipMemcpyDeviceToDevice, e->own_stream));
+    U2HIP(hipGraphLaunch(e->gexec, e->own_stream));
+    U2HIP(hipMemcpyAsync(prob_out, e->o_prob, n * 4, hipMemcpyDeviceToDevice, e->own_stream));
+    if (norm_out) U2HIP(hipMemcpyAsync(norm_out, e->o_norm, n * 4, hipMemcpyDeviceToDevice, e->own_stream));
+    if (mask_out) U2HIP(hipMemcpyAsync(mask_out, e->o_mask, n, hipMemcpyDeviceToDevice, e->own_stream));
+    U2HIP(hipEventRecord(e->ev_out, e->own_stream));
+    U2HIP(hipStreamWaitEvent(st, e->ev_out, 0));
+    return YP_OK;
+}
+
+int yp_u2net_set_graph(yp_u2net* e, int enable) {
+    if (!e) return u2fail(YP_ERR_ARG, "null engine");
+    e->use_graph = enable != 0;
     return YP_OK;
 }
 

@@ -98,7 +98,7 @@ EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_we
            "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy",
            "yp_u2net_create", "yp_u2net_destroy", "yp_u2net_weight_count", "yp_u2net_weight_info", "yp_u2net_set_weight", "yp_u2net_finalize",
-           "yp_u2net_forward", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
+           "yp_u2net_forward", "yp_u2net_set_graph", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
 
 
 def _stream_ptr(device: torch.device) -> int:

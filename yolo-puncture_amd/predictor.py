@@ -108,74 +108,116 @@ class Masks:
     (yp_mask_contours) and only the polygon's few hundred points travel to the host; `.min_rect` is the rectangle
     `get_coord_min_rect_len` would derive from `.xy[i]` (reference yolo_seg/app.py:101-103)."""
 
-    def __init__(self, data: torch.Tensor, orig_shape: Tuple[int, int], u8: Optional[torch.Tensor] = None):
-        self.data = data
+    def __init__(self, data: Optional[torch.Tensor], orig_shape: Tuple[int, int], u8: Optional[torch.Tensor] = None):
+        if data is None and u8 is None:
+            raise ValueError("Masks needs data or u8")
+        self._data = data                 # float {0,1}; made from the uint8 masks on first use (the engine produces uint8)
         self.orig_shape = tuple(orig_shape)
         self._u8 = u8                     # the engine's uint8 masks (same pixels as data), kept for the device contour pass
-        self._xy = None
-        self._rect = None
+        self._polys: Dict[int, np.ndarray] = {}
+        self._rects: Dict[int, Tuple[float, float]] = {}
+
+    @property
+    def data(self):
+        if self._data is None:
+            self._data = self._u8.to(torch.float32)
+        return self._data
+
+    @property
+    def shape(self):
+        return tuple((self._data if self._data is not None else self._u8).shape)
 
     def cpu(self):
         m = Masks(self.data.cpu(), self.orig_shape, self._u8)
-        m._xy, m._rect = self._xy, self._rect
+        m._polys, m._rects = self._polys, self._rects
         return m
 
     def numpy(self):
-        m = Masks(self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else self.data, self.orig_shape, self._u8)
-        m._xy, m._rect = self._xy, self._rect
+        d = self.data
+        m = Masks(d.detach().cpu().numpy() if isinstance(d, torch.Tensor) else d, self.orig_shape, self._u8)
+        m._polys, m._rects = self._polys, self._rects
         return m
 
     def __len__(self):
-        return int(self.data.shape[0])
+        return int(self.shape[0])
 
     def __getitem__(self, i):
-        d = self.data[i]
         u = self._u8[i] if self._u8 is not None else None
-        return Masks(d[None] if d.ndim == 2 else d, self.orig_shape, u[None] if (u is not None and u.dim() == 2) else u)
+        if u is not None and u.dim() == 2:
+            u = u[None]
+        d = None
+        if self._data is not None:
+            d = self._data[i]
+            d = d[None] if d.ndim == 2 else d
+        return Masks(d, self.orig_shape, u)
 
-    def _contours(self):
-        if self._xy is not None:
-            return
+    def _contour(self, i: int) -> np.ndarray:
+        """polygon of mask i (float32 [m,2], original-image pixels), computed on first use: the reference's loop touches ONE mask per
+        frame (`masks.xy[best]`, yolo_seg/app.py:101), so nothing is traced for the others."""
         n = len(self)
-        polys = [None] * n
-        rect = None
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        if i in self._polys:
+            return self._polys[i]
+        mh, mw = self.shape[1:]
+        poly, rect = None, None
         u8 = self._u8
-        if u8 is None and isinstance(self.data, torch.Tensor) and self.data.is_cuda:
-            u8 = (self.data > 0.5).to(torch.uint8)
-        if u8 is not None and u8.is_cuda and n > 0:
-            polys, rect = mask_contours_device(u8)
-        mh, mw = (int(v) for v in self.data.shape[1:])
-        host = None
-        out = []
-        for i in range(n):
-            poly = polys[i]
-            if poly is None:                              # (no GPU copy, or the device pass declined this mask: host trace)
-                if host is None:
-                    host = self.data.detach().cpu().numpy() if isinstance(self.data, torch.Tensor) else np.asarray(self.data)
-                poly = hostops.largest_external_contour(host[i] > 0.5)
-                if rect is not None:
-                    rect[i] = hostops.min_area_rect_size(poly) if poly.shape[0] else (0.0, 0.0)
-            if poly.shape[0] and (mh, mw) != self.orig_shape:
-                poly = hostops.scale_coords((mh, mw), poly, self.orig_shape)
-            out.append(poly.astype(np.float32))
-        self._xy = out
-        self._rect = rect if (mh, mw) == self.orig_shape else None      # (the rectangle is of the polygon in mask pixels)
+        if u8 is None and isinstance(self._data, torch.Tensor) and self._data.is_cuda:
+            u8 = (self._data[i:i + 1] > 0.5).to(torch.uint8)
+            polys, rects = mask_contours_device(u8)
+            poly, rect = polys[0], rects[0]
+        elif u8 is not None and u8.is_cuda:
+            polys, rects = mask_contours_device(u8[i:i + 1])
+            poly, rect = polys[0], rects[0]
+        if poly is None:                                  # (no GPU copy, or the device pass declined this mask: host trace)
+            d = self.data[i]
+            host = d.detach().cpu().numpy() if isinstance(d, torch.Tensor) else np.asarray(d)
+            poly = hostops.largest_external_contour(host > 0.5)
+            rect = None
+        if rect is not None and (mh, mw) == self.orig_shape:
+            self._rects[i] = (float(rect[0]), float(rect[1]))   # (the device rectangle is of the polygon in mask pixels)
+        if poly.shape[0] and (mh, mw) != self.orig_shape:
+            poly = hostops.scale_coords((mh, mw), poly, self.orig_shape)
+        self._polys[i] = poly.astype(np.float32)
+        return self._polys[i]
 
     @property
-    def xy(self) -> List[np.ndarray]:
-        self._contours()
-        return self._xy
+    def xy(self) -> "_LazyPolygons":
+        return _LazyPolygons(self)
 
     def min_rect_len(self, i: int):
         """(length, length / width) exactly as `get_coord_min_rect_len(self.xy[i])` returns them (yolo_seg/utils/mask_tools.py:12-22),
         from the device rectangle when there is one."""
-        self._contours()
-        if self._rect is None or len(self._xy[i]) < 3:
-            return hostops.get_coord_min_rect_len(self._xy[i])
-        length, width = float(self._rect[i][0]), float(self._rect[i][1])
+        poly = self._contour(i)
+        if i < 0:
+            i += len(self)
+        if i not in self._rects or len(poly) < 3:
+            return hostops.get_coord_min_rect_len(poly)
+        length, width = self._rects[i]
         if width == 0:
             width = 1
         return length, length / width
+
+
+class _LazyPolygons:
+    """What `Masks.xy` returns: behaves like the list of polygons ultralytics builds (len, indexing, slicing, iteration), but a
+    polygon is traced only when it is asked for."""
+
+    def __init__(self, masks: Masks):
+        self._m = masks
+
+    def __len__(self):
+        return len(self._m)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self._m._contour(j) for j in range(*i.indices(len(self._m)))]
+        return self._m._contour(int(i))
+
+    def __iter__(self):
+        return (self._m._contour(j) for j in range(len(self._m)))
 
 
 class Results:
@@ -290,10 +332,6 @@ class YOLO:
         eng = _ENGINE_CACHE.get(key)
         if eng is None:
             eng = Engine(self.variant, self.nc, self.seg, self.dtype, self._dev_index, state=self._state, family=self.family)
-            # the reference's real workload is one frame per call (yolo_seg/app.py:85-91): ~90 eager launches per frame would be
-            # launch-bound, so the forward is replayed as one hipGraph per input shape (the engine runs every new shape once eagerly
-            # before it captures; the graph is keyed on the input pointer, hence the persistent batch buffers below)
-            eng.set_graph(os.environ.get("YOLOP_PREDICT_GRAPH", "1") != "0")
             _ENGINE_CACHE[key] = eng
         return eng
 
@@ -335,6 +373,10 @@ class YOLO:
             # one output set per batch size (no allocation per call); everything handed to the caller below is copied out of it
             cache = self.__dict__.setdefault("_out_cache", {})
             okey = (self._dev_index, len(idxs))
+            # hipGraph replay pays from a handful of frames per call upwards; for the reference's one-frame calls (yolo_seg/app.py:85-91)
+            # eager launches pipeline better (measured, profiles/r02_latency_b1.json: 0.62 ms eager vs 0.68 ms replay per frame)
+            gmin = int(os.environ.get("YOLOP_PREDICT_GRAPH_MIN_BATCH", "8"))
+            eng.set_graph(gmin > 0 and len(idxs) >= gmin)
             out = eng.forward(batch, cache.get(okey))
             cache[okey] = out
             det = out["det"]
@@ -354,7 +396,7 @@ class YOLO:
                         m, _, _ = eng.masks(bi, cf, d[:, :4], (oh, ow), retina=True)
                     else:
                         m, _, _ = eng.masks(bi, cf, boxes_in, (H, W), retina=False)
-                    masks = Masks(m.to(torch.float32), (oh, ow), u8=m)
+                    masks = Masks(None, (oh, ow), u8=m)
                 out_by_index[i] = Results(imgs[i], Boxes(d, (oh, ow)), masks, self.names, paths[i])
         for i in range(len(imgs)):
             results.append(out_by_index[i])

@@ -103,6 +103,8 @@ def _declare(lib: C.CDLL) -> None:
     lib.yp_u2net_set_weight.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int]
     lib.yp_u2net_finalize.argtypes = [vp]
     lib.yp_u2net_forward.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]
+    lib.yp_u2net_set_graph.argtypes = [vp, C.c_int]
+    lib.yp_u2net_set_graph.restype = C.c_int
     lib.yp_u2net_tensor_count.argtypes = [vp]
     lib.yp_u2net_tensor_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     lib.yp_u2net_tensor_read.argtypes = [vp, C.c_int, vp]
@@ -162,6 +164,9 @@ class U2NetEngine:
 
     def finalize(self) -> None:
         self._chk(self.lib.yp_u2net_finalize(self._h))
+
+    def set_graph(self, enable: bool) -> None:
+        self._chk(self.lib.yp_u2net_set_graph(self._h, 1 if enable else 0))
 
     def forward(self, im_bgr: torch.Tensor, want_mask: bool = True):
         """im_bgr uint8 cuda [B,H,W,3] (BGR, as cv2 frames are) -> (prob float32 [B,H,W] = sigmoid(d0), norm float32 [B,H,W] = normPRED(prob)
