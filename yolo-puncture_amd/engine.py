@@ -125,7 +125,7 @@ def letterbox_device(src: torch.Tensor, geo: dict, out: Optional[torch.Tensor] =
     return out
 
 
-def mask_contours_device(masks: torch.Tensor, max_pts: int = 4096, want_rect: bool = True):
+def mask_contours_device(masks: torch.Tensor, max_pts: int = 16384, want_rect: bool = True):
     """yp_mask_contours: uint8 cuda [n,H,W] -> (list of int32 [m,2] numpy polygons (None where the device path declined), rect float64 [n,2]
     numpy (long side, short side) or None). One small D2H of the points; the masks stay on the device."""
     if not (masks.is_cuda and masks.dtype == torch.uint8 and masks.dim() == 3):
