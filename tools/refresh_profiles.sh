@@ -21,6 +21,10 @@ cp $O/traffic_latest.json $R/profiles/traffic_latest.json
 rm -rf $O/stats $O/fetch $O/write
 echo "[refresh] traffic done"
 python3 $R/tools/profile_ops.py > $O/per_op_table.txt 2>&1
+echo "[refresh] per-op table done"
 python3 $R/bench.py > $O/bench.log 2>&1                   # final line, with the fresh traffic json in place
 tail -1 $O/bench.log > $O/bench.json
+$R/tools/micro/peak_bench > $O/micro_peak_bench.txt 2>&1 || true
+python3 $R/tools/latency_b1.py > $O/latency_b1.json 2> $O/latency_b1.err || true
+echo "[refresh] peaks + latency done"
 cat $O/bench.json
