@@ -1,6 +1,6 @@
 """YOLOv10 architecture arithmetic used by the host side (weight naming/shapes, variant detection).
 
-The executable graph itself is built natively by the engine (csrc/graph.cpp) from the same scale table;
+The executable graph itself is built natively by the engine (csrc/engine.hip: build_graph) from the same scale table;
 this module only resolves channel widths / repeats per variant. Spec: SURVEY.md Appendix A.1/A.3/A.4 [U]
 (the `ultralytics` yaml + parse_model rules behind `YOLO(path)`, reference yolo_seg/app.py:45).
 """
