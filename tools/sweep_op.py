@@ -18,7 +18,7 @@ im = torch.randint(0, 256, (a.batch, 640, 640, 3), dtype=torch.uint8).cuda()
 out = eng.forward(im); torch.cuda.synchronize()
 ops = eng.plan(a.batch, 640, 640)
 lines = []
-cfgs = list(range(14)) + [100, 101, 102, 103] + [200, 201, 202, 203, 204] + list(range(300, 341)) + list(range(400, 409)) + list(range(500, 505)) + [600, 601] + list(range(700, 713))
+cfgs = list(range(14)) + [100, 101, 102, 103] + [200, 201, 202, 203, 204] + list(range(300, 341)) + list(range(400, 409)) + list(range(500, 505)) + [600, 601] + list(range(700, 713)) + list(range(800, 808))
 if a.cfgs: cfgs = [int(x) for x in a.cfgs.split(',')]
 for name in a.ops.split(","):
     idx = [i for i, o in enumerate(ops) if o["name"] == name][0]

@@ -250,6 +250,11 @@ int conv_tile1_num_cfgs();
 bool conv_tile1_cfg_valid(const ConvParams& p, int c);
 const char* conv_tile1_kernel_name(int c);
 hipError_t launch_conv_tile1(const ConvParams& p, int c, hipStream_t st);
+// pixels-direct 1x1 kernel (conv_pxd.hip); ids offset by 800
+int conv_pxd_num_cfgs();
+bool conv_pxd_cfg_valid(const ConvParams& p, int c);
+const char* conv_pxd_kernel_name(int c);
+hipError_t launch_conv_pxd(const ConvParams& p, int c, hipStream_t st);
 // weights-in-registers 3x3 s1 kernel (conv_wreg.hip); ids offset by 700
 int conv_wreg_num_cfgs();
 bool conv_wreg_cfg_valid(const ConvParams& p, int c);
