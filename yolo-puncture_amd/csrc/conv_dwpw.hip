@@ -361,7 +361,12 @@ bool conv_dwpw_valid(const DwPwParams& p) {
     if ((p.C % 32) != 0 || p.Kpad != p.C || (p.Cout & 3) || (p.y_stride & 3) || (p.y_coff & 3)) return false;
     if (p.x_bytes >= (1ull << 31) || p.y_bytes >= (1ull << 31) || p.wpw_bytes >= (1ull << 31)) return false;
     if ((long)((p.H + 7) / 8 * 8) * ((p.W + 15) / 16 * 16) * 2 > (long)p.H * p.W * 3) return false;
-    return dwpw_bn(p) != 0;
+    const int bn = dwpw_bn(p);
+    if (bn == 0) return false;
+    // every output-channel block repeats the depthwise stage: with more than two blocks (v10-X: 320 -> 640 in 64-wide blocks) the
+    // fused form costs more than the two kernels it replaces (measured 72 us vs ~35 us per pair at 40x40, bs 8)
+    if ((p.Cout + bn - 1) / bn > 2) return false;
+    return true;
 }
 
 const char* conv_dwpw_kernel_name(const DwPwParams& p) {

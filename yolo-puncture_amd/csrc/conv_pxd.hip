@@ -52,7 +52,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_pxd_kernel(const ConvPara
     }
     const int mt = bid % mtiles, nt = bid / mtiles;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int nk = p.Kpad / BK;
+    const int nk = (p.Kpad + BK - 1) / BK;            // Kpad % 32 == 0: a trailing half step reads zero pixels (its weight bytes are then irrelevant)
 
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_pxd_kernel(const ConvPara
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const unsigned base = src2 ? xoff2[f] : xoff[f];
-                const unsigned voff = (live && base != OOB) ? base + (unsigned)(k0 + s * 32) * 2u : OOB;
+                const unsigned voff = (live && base != OOB && k0 + s * 32 < p.Kpad) ? base + (unsigned)(k0 + s * 32) * 2u : OOB;
                 asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst[f][s]) : "v"(voff), "s"(rs) : "memory");
             }
     };
@@ -239,7 +239,7 @@ int conv_pxd_num_cfgs() { return kNumPxd; }
 bool conv_pxd_cfg_valid(const ConvParams& p, int c) {
     if (c < 0 || c >= kNumPxd) return false;
     const PxdCfg& k = kPxd[c];
-    if (p.ks != 1 || p.stride != 1 || p.up != 1 || p.w2 || (p.Cin % 64) != 0 || p.Kpad != p.Cin) return false;
+    if (p.ks != 1 || p.stride != 1 || p.up != 1 || p.w2 || (p.Cin % 32) != 0 || p.Kpad != p.Cin) return false;
     if ((p.x_stride & 7) || (p.x_coff & 7)) return false;                                  // 16-byte fragment loads
     if (p.x2_C > 0 && ((p.x2_C % 64) != 0 || (p.x2_stride & 7) || (p.x2_coff & 7))) return false;
     if (p.x_bytes >= (1ull << 31) || p.w_bytes >= (1ull << 31) || p.y_bytes >= (1ull << 31) || (p.x2_C > 0 && p.x2_bytes >= (1ull << 31))) return false;
