@@ -44,6 +44,8 @@ struct TensorDesc {
 struct WeightDesc {
     std::string name;    // folded name, e.g. "model.2.cv1" ; parameters "<name>.weight" / "<name>.bias"
     int cout = 0, cin_g = 0, k = 1, groups = 1;
+    int cin_pad = 0;           // dense convs: channels per tap in the PACKED matrix (= cin_g rounded up to 32 when that is not a multiple of 32
+                               // and > 32; zero weights in the gap) - the conv kernels then run with Cin = cin_pad, see engine.hip conv_params
     bool transposed = false;   // ConvTranspose2d layout [Cin][Cout][k][k]
     bool is_stem = false;
     bool have_w = false, have_b = false;

@@ -127,8 +127,14 @@ struct Builder {
     int weight(const std::string& name, int cout, int cin_g, int k, int groups, bool transposed = false, bool stem = false) {
         WeightDesc w;
         w.name = name; w.cout = cout; w.cin_g = cin_g; w.k = k; w.groups = groups; w.transposed = transposed; w.is_stem = stem;
+        w.cin_pad = cin_g;
+        // Channel counts such as 80 or 400 (v10-X / -M) are not multiples of the 32-deep operand chunk: the LDS-DMA kernels would be out,
+        // leaving conv_igemm. Packing the weights with each tap's channels padded to 32 (zeros in the gap) lets every kernel run with
+        // Cin = cin_pad: the extra 16 channels it reads per pixel are the NEXT pixel's (or slice's) first ones - finite values (the arena is
+        // zero-filled when allocated) times zero weights.
+        if (e.dtype == DT_BF16 && !stem && groups == 1 && !transposed && cin_g > 32 && (cin_g % 32) != 0 && (cin_g % 8) == 0) w.cin_pad = (cin_g + 31) / 32 * 32;
         if (!stem && groups == 1) {         // packed GEMM geometry (pack_weight fills exactly this): known from the shape alone, so a plan
-            const int K = transposed ? cin_g : k * k * cin_g;       // made before yp_finalize takes the same decisions as one made after
+            const int K = transposed ? cin_g : k * k * w.cin_pad;   // made before yp_finalize takes the same decisions as one made after
             w.Kpad = (K + 31) / 32 * 32;
             w.mat_bytes = (size_t)((cout + 127) / 128 * 128) * w.Kpad * e.es();
         }
@@ -782,10 +788,12 @@ static int allocate_plan(yp_engine& e) {
     size_t total = 0;
     for (auto& t : e.tensors) total += (t.bytes + 255) & ~(size_t)255;
     HIPCHK(hipSetDevice(e.device));
+    total += 4096;                                   // (slack behind the last tensor: padded-tap reads of conv_igemm's plain loads)
     if (total > e.arena_bytes) {
         if (e.arena) HIPCHK(hipFree(e.arena));
         e.arena = nullptr;
         HIPCHK(hipMalloc(&e.arena, total));
+        HIPCHK(hipMemset(e.arena, 0, total));        // every byte a kernel may over-read is a finite number from here on
         e.arena_bytes = total;
     }
     size_t off = 0;
@@ -854,6 +862,7 @@ static ConvParams conv_params(const yp_engine& e, const Op& o) {
     const TensorDesc &ti = e.tensors[o.in.t], &to = e.tensors[o.out.t];
     ConvParams p{};
     p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.H = ti.H; p.W = ti.W; p.Cin = o.in.C;
+    if (w.cin_pad > o.in.C) p.Cin = w.cin_pad;      // (packed with padded taps: the kernels read cin_pad channels per pixel)
     p.w = w.d_w; p.Kpad = w.Kpad; p.bias = w.d_b;
     p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff; p.Ho = to.H; p.Wo = to.W; p.Cout = o.out.C;
     if (o.res.t >= 0) { p.res = e.tensors[o.res.t].ptr; p.res_stride = e.tensors[o.res.t].C; p.res_coff = o.res.coff; }
@@ -1426,8 +1435,8 @@ static void pack_weight(const yp_engine& e, WeightDesc& w, std::vector<unsigned 
                         put(main, sub * (dy * 2 + dx) + (size_t)co * w.Kpad + ci, w.w[(((size_t)ci * cout + co) * 2 + dy) * 2 + dx], e.dtype);
     } else {
         // dense: [Cout][Cin][k][k] -> [CoutPad128][Kpad], k order (ky,kx,ci)
-        const int cin = w.cin_g, cout = w.cout, k = w.k;
-        const int K = k * k * cin;
+        const int cin = w.cin_g, cout = w.cout, k = w.k, cp = w.cin_pad > 0 ? w.cin_pad : cin;
+        const int K = k * k * cp;
         w.Kpad = (K + 31) / 32 * 32;
         const size_t rows = (size_t)(cout + 127) / 128 * 128;
         w.mat_bytes = rows * w.Kpad * es;
@@ -1436,7 +1445,7 @@ static void pack_weight(const yp_engine& e, WeightDesc& w, std::vector<unsigned 
             for (int ci = 0; ci < cin; ++ci)
                 for (int ky = 0; ky < k; ++ky)
                     for (int kx = 0; kx < k; ++kx)
-                        put(main, (size_t)co * w.Kpad + (size_t)(ky * k + kx) * cin + ci, w.w[(((size_t)co * cin + ci) * k + ky) * k + kx], e.dtype);
+                        put(main, (size_t)co * w.Kpad + (size_t)(ky * k + kx) * cp + ci, w.w[(((size_t)co * cin + ci) * k + ky) * k + kx], e.dtype);
     }
 }
 
