@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Run U^2-Net-P forward N times on a 380x380 crop (for rocprofv3 --kernel-trace --stats)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from yolo_puncture_amd.u2net import U2NetEngine, synthetic_state
+dt = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+e = U2NetEngine("p", dt, 0, state=synthetic_state("p", 0))
+e.set_graph(False)
+x = torch.randint(0, 256, (1, 380, 380, 3), dtype=torch.uint8).cuda()
+for _ in range(20):
+    e.forward(x)
+torch.cuda.synchronize()
+e.close()
