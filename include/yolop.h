@@ -148,7 +148,7 @@ int yp_u2net_set_weight(yp_u2net* e, const char* name, const float* host, const 
 int yp_u2net_finalize(yp_u2net* e);
 int yp_u2net_forward(yp_u2net* e, const uint8_t* bgr_dev, int B, int H, int W, float* prob_out, float* norm_out,
                      uint8_t* mask_out, void* stream);
-int yp_u2net_set_graph(yp_u2net* e, int enable);   /* hipGraph replay of the forward (default on; the first pass of a shape is always eager) */
+int yp_u2net_set_graph(yp_u2net* e, int enable);   /* hipGraph replay of the forward (default off: measured slower than eager launches; the first pass of a shape is always eager) */
 int yp_u2net_tensor_count(const yp_u2net* e);
 int yp_u2net_tensor_info(const yp_u2net* e, int i, char* name, int name_cap, int dims[4] /*B,H,W,C*/);
 int yp_u2net_tensor_read(yp_u2net* e, int i, float* host_out);   /* sync copy NHWC -> fp32 host (debug taps) */

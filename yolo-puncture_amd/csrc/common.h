@@ -114,6 +114,9 @@ struct ConvParams {
     const void* w2; const float* bias2; int C2, act2, Kpad2; size_t w2_bytes;
     unsigned long long* clk;                    // debug (YOLOP_LC_CLOCKS=1, conv_dma_lc only): per-wave phase clocks, else null
     int dil;                                    // dilation of a 3x3 (0 = 1); conv_igemm only - the U^2-Net path (pad = dil there)
+    // conv_small only: x is the tensor IN FRONT OF a 2x2 / stride-2 / ceil-mode max pool (src_H x src_W pixels) and the pool is taken
+    // while loading; H, W stay the pooled size the convolution sees
+    int pool_in, src_H, src_W;
 };
 
 struct DwParams {
@@ -287,6 +290,9 @@ bool dwconv_mfma_valid(const DwParams& p, int dtype);
 hipError_t launch_dwconv_mfma(const DwParams& p, hipStream_t st);
 hipError_t launch_upsample(const UpParams& p, int dtype, hipStream_t st);
 hipError_t launch_attention(const AttnParams& p, int dtype, hipStream_t st);
+// conv_small.hip: fp32 3x3 for small maps (four waves split K, operands straight from L2)
+bool conv_small_valid(const ConvParams& p, int dtype);
+hipError_t launch_conv_small(const ConvParams& p, int dtype, hipStream_t st);
 hipError_t launch_head(const HeadParams& p, hipStream_t st);
 hipError_t launch_letterbox(const uint8_t* src, int h0, int w0, uint8_t* dst, int out_h, int out_w, int new_h, int new_w, int top,
                             int left, int pad, hipStream_t st);

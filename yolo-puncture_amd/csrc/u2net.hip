@@ -64,6 +64,10 @@ struct U2Op {
     std::string name;
     View in, out, res;
     int widx = -1, dil = 1, act = ACT_RELU;
+    int impl = -1;         // convs: -1 = not yet chosen for this plan, 0 = conv_igemm, 1 = conv_small, 2 = conv_small taking the max pool in
+                           // front of it while loading (tuned in the plan's first pass)
+    int pool_op = -1;      // convs: index of the pool op that produces this conv's input and feeds nothing else (graph pass)
+    int consumer = -1;     // pools: index of that conv; the pool does not launch while the conv runs with impl 2
 };
 
 }  // namespace
@@ -77,13 +81,16 @@ struct yp_u2net {
     int side_t[6] = {-1, -1, -1, -1, -1, -1};
     int outconv_w = -1;
     bool finalized = false;
+    // conv_small.hip vs conv_igemm.hip per convolution: small_max < 0 = timed per layer in a plan's first pass (default), otherwise
+    // conv_small takes every layer it can run with at most small_max output pixels (YOLOP_U2_SMALL_MAX; 0 = never). Read at create.
+    long small_max = -1;
     int pB = 0, pH = 0, pW = 0;
     void* arena = nullptr;
     size_t arena_bytes = 0;
     float* d_fuse = nullptr;            // [6 weights | bias | min bits | max bits]
     // hipGraph replay (the crop is launch-bound: ~170 small kernels): the graph reads an engine-owned copy of the frame and writes
     // engine-owned results, so neither the caller's input nor its output pointers are baked in; both copies ride the same stream
-    bool use_graph = true, warmed = false;
+    bool use_graph = false, warmed = false;      // replay measured slower than eager launches on this net (2.29 vs 2.08 ms at 380^2): off by default
     hipStream_t own_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -226,6 +233,25 @@ static int build_u2net(yp_u2net& e) {
         e.side_t[k] = st;
     }
     e.outconv_w = B.weight("outconv", 1, 6, 1);
+    // graph pass: a max pool whose output is read by exactly one op, a convolution over the whole pooled tensor, may be taken by that
+    // convolution while loading (conv_small's POOL form); whether it is, is decided per plan (u2_tune_op)
+    for (size_t i = 0; i < e.ops.size(); ++i) {
+        if (e.ops[i].kind != U2_POOL) continue;
+        const int t = e.ops[i].out.t;
+        int readers = 0, conv = -1;
+        for (size_t j = 0; j < e.ops.size(); ++j) {
+            const U2Op& o = e.ops[j];
+            if (j != i && (o.in.t == t || o.res.t == t)) { ++readers; conv = (int)j; }
+        }
+        bool side = false;
+        for (int k = 0; k < 6; ++k) side = side || e.side_t[k] == t;
+        if (readers != 1 || side || conv < (int)i) continue;
+        U2Op& c = e.ops[conv];
+        if (c.kind != U2_CONV || c.in.t != t || c.in.coff != 0 || c.in.C != e.tensors[t].C || c.res.t == t) continue;
+        if (e.ops[i].out.coff != 0 || e.ops[i].out.C != e.tensors[t].C) continue;
+        c.pool_op = (int)i;
+        e.ops[i].consumer = conv;
+    }
     return YP_OK;
 }
 
@@ -401,6 +427,7 @@ static int plan_u2(yp_u2net& e, int B, int H, int W) {
     size_t off = 0;
     for (auto& t : e.tensors) { t.ptr = (char*)e.arena + off; off += (t.bytes + 255) & ~(size_t)255; }
     e.pB = B; e.pH = H; e.pW = W;
+    for (auto& o : e.ops) o.impl = -1;
     if (e.gexec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(e.gexec); e.gexec = nullptr; }
     return YP_OK;
 }
@@ -425,8 +452,7 @@ static hipError_t run_small(const yp_u2net& e, const U2Op& o, const uint8_t* img
     return hipGetLastError();
 }
 
-static hipError_t run_u2_op(const yp_u2net& e, const U2Op& o, const uint8_t* img, hipStream_t st) {
-    if (o.kind != U2_CONV) return e.dtype == DT_BF16 ? run_small<__bf16>(e, o, img, st) : run_small<float>(e, o, img, st);
+static ConvParams u2_conv_params(const yp_u2net& e, const U2Op& o, bool fuse_pool = false) {
     const U2Weight& w = e.weights[o.widx];
     const U2Tensor &ti = e.tensors[o.in.t], &to = e.tensors[o.out.t];
     ConvParams p{};
@@ -438,7 +464,66 @@ static hipError_t run_u2_op(const yp_u2net& e, const U2Op& o, const uint8_t* img
     p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
     p.up = 1; p.cfg = -1;
     p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.y_bytes = to.bytes;
-    return launch_conv_igemm(p, e.dtype, st);
+    if (fuse_pool) {                                   // read the pool's input instead; H, W stay the pooled size
+        const U2Op& po = e.ops[o.pool_op];
+        const U2Tensor& ts = e.tensors[po.in.t];
+        p.x = ts.ptr; p.x_stride = ts.C; p.x_coff = po.in.coff; p.x_bytes = ts.bytes;
+        p.pool_in = 1; p.src_H = ts.H; p.src_W = ts.W;
+    }
+    return p;
+}
+
+// untuned choice: the K-split kernel (conv_small.hip) up to `small_max` output pixels
+static int u2_default_impl(const yp_u2net& e, const ConvParams& p) {
+    const long cap = e.small_max >= 0 ? e.small_max : 40000L;
+    return ((long)p.M <= cap && conv_small_valid(p, e.dtype)) ? 1 : 0;
+}
+
+static hipError_t run_u2_op(const yp_u2net& e, const U2Op& o, const uint8_t* img, hipStream_t st) {
+    if (o.kind == U2_POOL && o.consumer >= 0 && e.ops[o.consumer].impl == 2) return hipSuccess;      // taken by its consumer while loading
+    if (o.kind != U2_CONV) return e.dtype == DT_BF16 ? run_small<__bf16>(e, o, img, st) : run_small<float>(e, o, img, st);
+    const int impl = o.impl >= 0 ? o.impl : 0;
+    const ConvParams p = u2_conv_params(e, o, impl == 2);
+    return impl >= 1 ? launch_conv_small(p, e.dtype, st) : launch_conv_igemm(p, e.dtype, st);
+}
+
+// First pass of a plan: every convolution that both kernels can run is timed with both on its real input (the ops before it have
+// run), the faster one is kept for this plan. An op rewrites the same output from the same inputs, so repeating it is harmless.
+static int u2_tune_op(yp_u2net& e, U2Op& o, hipStream_t st) {
+    const ConvParams p = u2_conv_params(e, o);
+    if (!conv_small_valid(p, e.dtype)) { o.impl = 0; return YP_OK; }
+    static const bool fuse_pool = [] { const char* s = getenv("YOLOP_U2_FUSE_POOL"); return !(s && s[0] == '0'); }();
+    const bool can_fuse = fuse_pool && o.pool_op >= 0 && conv_small_valid(u2_conv_params(e, o, true), e.dtype);
+    if (e.small_max >= 0) { o.impl = u2_default_impl(e, p) ? (can_fuse ? 2 : 1) : 0; return YP_OK; }
+    hipEvent_t e0, e1;
+    U2HIP(hipEventCreate(&e0));
+    U2HIP(hipEventCreate(&e1));
+    float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};          // igemm, small, small + pool, the pool launch alone
+    for (int v = 0; v < 4; ++v) {
+        if ((v == 2 || v == 3) && !can_fuse) continue;
+        const ConvParams pv = u2_conv_params(e, o, v == 2);
+        for (int rep = 0; rep < 4; ++rep) {              // rep 0 warms (code object, caches)
+            U2HIP(hipEventRecord(e0, st));
+            hipError_t err;
+            if (v == 3) err = e.dtype == DT_BF16 ? run_small<__bf16>(e, e.ops[o.pool_op], nullptr, st) : run_small<float>(e, e.ops[o.pool_op], nullptr, st);
+            else err = v >= 1 ? launch_conv_small(pv, e.dtype, st) : launch_conv_igemm(pv, e.dtype, st);
+            if (err != hipSuccess) return u2fail(YP_ERR_HIP, "tuning launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
+            U2HIP(hipEventRecord(e1, st));
+            U2HIP(hipEventSynchronize(e1));
+            float ms = 0.f;
+            U2HIP(hipEventElapsedTime(&ms, e0, e1));
+            if (rep > 0 && ms < best[v]) best[v] = ms;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    o.impl = best[1] < best[0] ? 1 : 0;
+    if (can_fuse && best[2] < best[o.impl] + best[3]) o.impl = 2;
+    static const char* names[3] = {"igemm", "small", "small+pool"};
+    if (getenv("YOLOP_U2_TUNE_LOG")) fprintf(stderr, "[u2 tune] %-28s M %7d Cin %3d Cout %2d dil %d: igemm %.1f us, small %.1f us, small+pool %.1f us (pool alone %.1f us) -> %s\n",
+                                             o.name.c_str(), p.M, p.Cin, p.Cout, p.dil, best[0] * 1e3f, best[1] * 1e3f, can_fuse ? best[2] * 1e3f : 0.f,
+                                             can_fuse ? best[3] * 1e3f : 0.f, names[o.impl]);
+    return YP_OK;
 }
 
 static void u2_put(std::vector<unsigned char>& buf, size_t idx, float v, int dtype) {
@@ -464,6 +549,7 @@ int yp_u2net_create(int variant, int dtype, int device, yp_u2net** out) {
     if (dtype != YP_BF16 && dtype != YP_F32) return u2fail(YP_ERR_ARG, "bad dtype");
     std::unique_ptr<yp_u2net> e(new yp_u2net());
     e->variant = variant; e->dtype = dtype; e->device = device;
+    if (const char* sm = getenv("YOLOP_U2_SMALL_MAX")) e->small_max = atol(sm);
     const int rc = build_u2net(*e);
     if (rc != YP_OK) return rc;
     *out = e.release();
@@ -551,7 +637,11 @@ int yp_u2net_finalize(yp_u2net* e) {
 }
 
 static int u2_run(yp_u2net* e, const uint8_t* bgr, float* prob, float* norm, uint8_t* mask, hipStream_t st) {
-    for (const U2Op& o : e->ops) {
+    for (U2Op& o : e->ops) {
+        if (o.kind == U2_CONV && o.impl < 0) {             // (never under a capture: a plan's first pass is eager)
+            const int rc = u2_tune_op(*e, o, st);
+            if (rc != YP_OK) return rc;
+        }
         hipError_t err = run_u2_op(*e, o, bgr, st);
         if (err != hipSuccess) return u2fail(YP_ERR_HIP, "launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
     }
