@@ -237,6 +237,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
 // which instantiation launch_conv picks (also reported to the profiler/bench through yp_op_kernel)
 static int conv_tile_choice(const ConvParams& p) {
+    if (p.Cout <= 16) return 3;          // U^2-Net's 16-channel (and 1-channel side) layers: a 32-wide tile wastes half its MFMAs
     if (p.Cout <= 32) return 0;
     if ((p.Cout % 128) != 0 || p.M < 128 * 256) return 1;
     return 2;
@@ -283,9 +284,9 @@ const char* conv_kernel_name(const ConvParams& p, int dtype) {
     if (h >= 200) return conv_halo_p_kernel_name(h - 200);
     if (h >= 100) return conv_halo_kernel_name(h - 100);
     if (dtype == DT_BF16 && conv_dma_supported(p)) return conv_dma_kernel_name(p);
-    static const char* names[2][3] = {
-        {"conv_igemm_kernel<bf16,128,32,4,1>", "conv_igemm_kernel<bf16,128,64,2,2>", "conv_igemm_kernel<bf16,128,128,2,2>"},
-        {"conv_igemm_kernel<f32,128,32,4,1>", "conv_igemm_kernel<f32,128,64,2,2>", "conv_igemm_kernel<f32,128,128,2,2>"}};
+    static const char* names[2][4] = {
+        {"conv_igemm_kernel<bf16,128,32,4,1>", "conv_igemm_kernel<bf16,128,64,2,2>", "conv_igemm_kernel<bf16,128,128,2,2>", "conv_igemm_kernel<bf16,128,16,4,1>"},
+        {"conv_igemm_kernel<f32,128,32,4,1>", "conv_igemm_kernel<f32,128,64,2,2>", "conv_igemm_kernel<f32,128,128,2,2>", "conv_igemm_kernel<f32,128,16,4,1>"}};
     return names[dtype == DT_BF16 ? 0 : 1][conv_tile_choice(p)];
 }
 
@@ -294,7 +295,10 @@ static hipError_t launch_conv_t(const ConvParams& p, hipStream_t st) {
     const int M = p.M;
     dim3 blk(256);
     const int choice = conv_tile_choice(p);
-    if (choice == 0) {
+    if (choice == 3) {
+        dim3 grid((M + 127) / 128, 1);
+        hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 16, 4, 1>), grid, blk, 0, st, p);
+    } else if (choice == 0) {
         dim3 grid((M + 127) / 128, 1);
         hipLaunchKernelGGL((conv_igemm_kernel<T, 128, 32, 4, 1>), grid, blk, 0, st, p);
     } else if (choice == 1) {
