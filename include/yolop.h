@@ -198,6 +198,9 @@ int yp_debug_ablation(int v);
 /* Profiling hook: 100 MHz timestamps of the phases of the top-k kernel (image 0's workgroup, last launch):
    [0] start, [1] keys loaded, [2] stage-1 select done, [3] stage-2 candidates scanned, [4] stage-2 select done, [5] decoded. */
 int yp_debug_head_clocks(uint64_t* out8);
+/* phase stamps of yp_mask_contours (mask 0): [0..6] 100-MHz ticks at box / bit image / candidates / trace / emit / hull / end, [8] candidates,
+   [9] points of the winning contour, [10], [11] bounding box width, height */
+int yp_debug_contour_clocks(uint64_t* out12);
 
 /* Host-only self-check of the executor for the current plan (parameter blocks, kernel symbols, tune-cache round trip, lane
  * schedule invariants). Needs no GPU; returns the number of scheduled launches or <0. Used by the CPU sanitizer build. */

@@ -29,11 +29,18 @@ struct ContourParams {
     int32_t* pts;              // [n][max_pts][2] (x, y) of the winning contour's run end points
     int32_t* count;            // [n] number of points (0: empty mask ; -1: bounding box too large for the LDS image ; -2: more than max_pts points / candidates)
     double* rect;              // [n][2] (long side, short side) of the minimum-area rectangle of those points, or null
+    int boxg;                  // workgroups per mask of the bounding-box pre-pass (their partial boxes sit at the head of the mask's `pts`)
 };
 
 // clockwise from east, as hostops._DIRS: (dy,dx)
-__device__ __constant__ int c_dy[8] = {0, 1, 1, 1, 0, -1, -1, -1};
-__device__ __constant__ int c_dx[8] = {1, 1, 0, -1, -1, -1, 0, 1};
+// (dy, dx) = {0,1,1,1,0,-1,-1,-1}, {1,1,0,-1,-1,-1,0,1}, each + 1 in two bits per direction: decoded in registers - a `__constant__` table indexed
+// per lane is a vector memory load, two of them on the serial path of every trace step (measured: 643 -> see DESIGN us per 720p mask)
+__device__ __forceinline__ int c_dy(int d) { return (int)((0x01a9u >> (2 * d)) & 3u) - 1; }
+__device__ __forceinline__ int c_dx(int d) { return (int)((0x901au >> (2 * d)) & 3u) - 1; }
+
+// phase stamps of mask 0's workgroup (s_memtime, 100 MHz) + [8] candidates, [9] points of the winner, [10] box width, [11] box height
+__device__ unsigned long long g_ct_clk[12];
+#define CT_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_ct_clk[i] = wall_clock64(); } while (0)
 
 struct Bitmap {
     const unsigned* w;   // LDS
@@ -53,19 +60,30 @@ struct Bitmap {
     }
 };
 
-// One Moore trace from (sy,sx). EMIT = false: returns the number of CHAIN_APPROX_SIMPLE points (0 = dropped: met an earlier pixel, or
-// longer than the step bound). EMIT = true: also writes the points (global, then bounding-box origin added).
+constexpr int CT_SLOT_PTS = 1024;           // points per emission slot (and of the list's head the winner is assembled in), when max_pts allows
+constexpr int CT_MAXSLOTS = 255;            // candidate k < slots emits into slot k of the mask's own `pts` region (regions 1 .. slots behind the head)
+constexpr int CT_BOXG = 32;                 // workgroups per mask of the bounding-box pre-pass (fewer when the point list is shorter than 64)
+
+// One Moore trace from (sy,sx), `max_steps` steps at most.
+// EMIT = false: returns the number of CHAIN_APPROX_SIMPLE points (0 = dropped: met an earlier pixel, or longer than the step bound) and
+//   whether the start point is one of them (`start_kept`: it is iff the last move differs from the first; _compress lists it first).
+// EMIT = true: additionally writes the kept points except the start point to out[0 .. cap) in trace order, bounding-box origin added
+//   (`*stored` = how many were kept; more than cap = the list overflowed). The counting pass gives every candidate with a slot its own
+//   list this way, so the winner's points are already in memory when it is known - tracing it a second time cost as much as the whole
+//   counting pass.
 template <bool EMIT>
-__device__ int moore_trace(const Bitmap& bm, int bw, int sy, int sx, int max_steps, int32_t* out, int max_pts, int ox, int oy) {
+__device__ int moore_trace(const Bitmap& bm, int bw, int sy, int sx, int max_steps, int32_t* out, int cap, int ox, int oy, int* start_kept, int* stored) {
     const int start_lin = sy * bw + sx;
     int cy = sy, cx = sx, d = 6;                 // "arrived" from the north-west side: start searching at north
     int start_d = -1, prev_move = -1, first_move = -1;
     int npts = 1, nkeep = 0;
     int px = sx, py = sy;                        // the point whose keep decision is pending: it is kept iff the moves before and after differ
+    *start_kept = 0;
+    if (EMIT) *stored = 0;
     for (int step = 0; step < max_steps; ++step) {
         const unsigned nbm = bm.nb(cy, cx);
         if (nbm == 0) {                           // isolated pixel
-            if (EMIT) { out[0] = sx + ox; out[1] = sy + oy; }
+            *start_kept = 1;
             return 1;
         }
         const unsigned rot = ((nbm >> d) | (nbm << (8 - d))) & 0xffu;
@@ -74,32 +92,30 @@ __device__ int moore_trace(const Bitmap& bm, int bw, int sy, int sx, int max_ste
         else if (cy == sy && cx == sx && nd == start_d) {
             // closed: pts[:-1] drops the repeated start, n = npts - 1 points, moves m_0..m_{n-1} (the last one returned to the start)
             const int n = npts - 1;
-            if (n <= 2) {                         // _compress keeps everything
-                if (EMIT) {
-                    out[0] = sx + ox; out[1] = sy + oy;
-                    if (n == 2) { out[2] = sx + c_dx[first_move] + ox; out[3] = sy + c_dy[first_move] + oy; }
+            if (n <= 2) {                         // _compress keeps everything: the start, then (n == 2) the pixel the first move leads to
+                *start_kept = 1;
+                if (EMIT && n == 2) {
+                    if (cap > 0) { out[0] = sx + c_dx(first_move) + ox; out[1] = sy + c_dy(first_move) + oy; }
+                    *stored = 1;
                 }
                 return n;
             }
+            if (EMIT) *stored = nkeep;
             // point 0 is kept iff the last move differs from the first one; the pending point (the start, reached by prev_move) is point 0
             if (prev_move != first_move) {
-                if (EMIT) {
-                    // point 0 must come first in the output: it was not emitted at the beginning, so the list is rotated by one here
-                    if (nkeep < max_pts) { out[2 * nkeep] = sx + ox; out[2 * nkeep + 1] = sy + oy; }
-                }
-                ++nkeep;
-                return EMIT ? -nkeep : nkeep;     // (EMIT: negative = "rotate right by one", see the caller)
+                *start_kept = 1;
+                return nkeep + 1;
             }
             return nkeep > 0 ? nkeep : 1;         // (all moves equal cannot happen on a closed trace; _compress would keep pts[0])
         }
         // take the move
         if (first_move < 0) first_move = nd;
         else if (nd != prev_move) {               // the point we are leaving (px,py) had a different move before it: kept
-            if (EMIT && nkeep < max_pts) { out[2 * nkeep] = px + ox; out[2 * nkeep + 1] = py + oy; }
+            if (EMIT && nkeep < cap) { out[2 * nkeep] = px + ox; out[2 * nkeep + 1] = py + oy; }
             ++nkeep;
         }
         prev_move = nd;
-        cy += c_dy[nd]; cx += c_dx[nd];
+        cy += c_dy(nd); cx += c_dx(nd);
         px = cx; py = cy;
         ++npts;
         if (cy * bw + cx < start_lin) return 0;  // not the raster-first pixel of its blob's outer border
@@ -108,37 +124,56 @@ __device__ int moore_trace(const Bitmap& bm, int bw, int sy, int sx, int max_ste
     return 0;
 }
 
+// Bounding-box pre-pass: CT_BOXG workgroups per mask, each over a contiguous 1/CT_BOXG of the pixels; the partial boxes go to the head
+// of the mask's `pts` region (consumed by contour_kernel before it writes anything there). One workgroup scanning a 1280x720 mask
+// alone took 93 us of the 600-us kernel.
+__global__ __launch_bounds__(256) void contour_bbox_kernel(const ContourParams p) {
+    __shared__ int s_box[4];
+    const int mi = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* M = p.masks + (size_t)mi * p.H * p.W;
+    if (tid == 0) { s_box[0] = p.W; s_box[1] = p.H; s_box[2] = -1; s_box[3] = -1; }
+    __syncthreads();
+    const size_t npix = (size_t)p.H * p.W;
+    const size_t per = ((npix + p.boxg - 1) / p.boxg + 15) & ~(size_t)15;
+    const size_t i0 = (size_t)g * per, i1 = min(npix, i0 + per);
+    int x0 = p.W, y0 = p.H, x1 = -1, y1 = -1;
+    for (size_t i = i0 + (size_t)tid * 16; i < i1; i += (size_t)256 * 16) {
+        unsigned any = 0;
+        const size_t e = min(i + 16, i1);
+        if (((uintptr_t)(M + i) & 15) == 0 && e == i + 16) {
+            const uint4 v = *(const uint4*)(M + i);
+            any = v.x | v.y | v.z | v.w;
+        } else {
+            for (size_t k = i; k < e; ++k) any |= M[k];
+        }
+        if (any)
+            for (size_t k = i; k < e; ++k)
+                if (M[k]) {
+                    const int y = (int)(k / p.W), x = (int)(k - (size_t)y * p.W);
+                    x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
+                }
+    }
+    if (x1 >= 0) { atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0); atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1); }
+    __syncthreads();
+    if (tid < 4) p.pts[(size_t)mi * p.max_pts * 2 + 4 * g + tid] = s_box[tid];
+}
+
 __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_box[4];                 // x0, y0, x1, y1 (inclusive)
     __shared__ int s_ncand;
     __shared__ unsigned long long s_best;    // (points << 32) | ~start_lin
     __shared__ int s_np, s_nhull;
+    __shared__ int s_win_slot, s_win_stored;  // the winner's slot (-1: it had none) and the points it stored there
     const int mi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint8_t* M = p.masks + (size_t)mi * p.H * p.W;
-    if (tid == 0) { s_box[0] = p.W; s_box[1] = p.H; s_box[2] = -1; s_box[3] = -1; s_ncand = 0; s_best = 0ull; s_np = 0; s_nhull = 0; }
+    if (tid == 0) { s_box[0] = p.W; s_box[1] = p.H; s_box[2] = -1; s_box[3] = -1; s_ncand = 0; s_best = 0ull; s_np = 0; s_nhull = 0; s_win_slot = -1; s_win_stored = 0; }
     __syncthreads();
-    // ---- 1a. bounding box -------------------------------------------------------------------------------------------
-    {
-        int x0 = p.W, y0 = p.H, x1 = -1, y1 = -1;
-        const size_t npix = (size_t)p.H * p.W;
-        for (size_t i = (size_t)tid * 16; i < npix; i += (size_t)CT_THREADS * 16) {
-            // 16 pixels per step (rows are not 16-aligned in general: byte loads through a 16-byte window when aligned, else scalar)
-            unsigned any = 0;
-            const size_t e = min(i + 16, npix);
-            if (((uintptr_t)(M + i) & 15) == 0 && e == i + 16) {
-                const uint4 v = *(const uint4*)(M + i);
-                any = v.x | v.y | v.z | v.w;
-            } else {
-                for (size_t k = i; k < e; ++k) any |= M[k];
-            }
-            if (any)
-                for (size_t k = i; k < e; ++k)
-                    if (M[k]) {
-                        const int y = (int)(k / p.W), x = (int)(k - (size_t)y * p.W);
-                        x0 = min(x0, x); x1 = max(x1, x); y0 = min(y0, y); y1 = max(y1, y);
-                    }
-        }
+    CT_STAMP(0);
+    // ---- 1a. bounding box: the partial boxes of contour_bbox_kernel ---------------------------------------------------------
+    if (tid < p.boxg) {
+        const int32_t* pb = p.pts + (size_t)mi * p.max_pts * 2 + 4 * tid;
+        const int x0 = pb[0], y0 = pb[1], x1 = pb[2], y1 = pb[3];
         if (x1 >= 0) { atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0); atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1); }
     }
     __syncthreads();
@@ -155,6 +190,7 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     }
     unsigned* bmw = (unsigned*)smem;
     int* cand = (int*)(smem + CT_BITMAP_BYTES);
+    CT_STAMP(1);
     // ---- 1b. bit image --------------------------------------------------------------------------------------------------
     for (int i = tid; i < (bh + 2) * pitch; i += CT_THREADS) bmw[i] = 0u;
     __syncthreads();
@@ -172,6 +208,7 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     }
     __syncthreads();
     Bitmap bm{bmw, pitch};
+    CT_STAMP(2);
     // ---- 2. candidates ----------------------------------------------------------------------------------------------------
     const int words_per_row = (bw + 31) / 32;
     for (int i = tid; i < bh * words_per_row; i += CT_THREADS) {
@@ -198,38 +235,60 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
         if (tid == 0) { p.count[mi] = -2; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
         return;
     }
+    CT_STAMP(3);
+    if (blockIdx.x == 0 && tid == 0) { g_ct_clk[8] = (unsigned long long)ncand; g_ct_clk[10] = (unsigned long long)bw; g_ct_clk[11] = (unsigned long long)bh; }
     // ---- 3. trace every candidate -------------------------------------------------------------------------------------------
     const int max_steps = 4 * bh * bw + 8;
+    int32_t* out = p.pts + (size_t)mi * p.max_pts * 2;
+    // the list's head (region 0) takes the result; regions 1 .. nslots behind it are the candidates' own lists
+    const int slot_cap = p.max_pts >= 8 * CT_SLOT_PTS ? CT_SLOT_PTS : p.max_pts / 8;
+    const int nslots = slot_cap >= 8 ? min(CT_MAXSLOTS, p.max_pts / slot_cap - 1) : 0;
+    int my_np = 0, my_stored = 0, my_k = -1;                        // (a thread traces at most one candidate with a slot: slots < CT_THREADS)
     for (int k = tid; k < ncand; k += CT_THREADS) {
         const int lin = cand[k];
         const int sy = lin / bw, sx = lin - sy * bw;
-        const int np = moore_trace<false>(bm, bw, sy, sx, max_steps, nullptr, 0, 0, 0);
-        if (np > 0) atomicMax(&s_best, ((unsigned long long)(unsigned)np << 32) | (unsigned)(~(unsigned)lin));
+        int kept0 = 0, stored = 0, np;
+        if (k < nslots) np = moore_trace<true>(bm, bw, sy, sx, max_steps, out + (size_t)(k + 1) * slot_cap * 2, slot_cap, bx0, by0, &kept0, &stored);
+        else np = moore_trace<false>(bm, bw, sy, sx, max_steps, nullptr, 0, bx0, by0, &kept0, &stored);
+        // most points wins, ties go to the first start in raster order; the low bit carries "the start point leads the list"
+        if (np > 0) atomicMax(&s_best, ((unsigned long long)(unsigned)np << 32) | ((unsigned long long)(0x7fffffffu - (unsigned)lin) << 1) | (unsigned)kept0);
+        if (k < nslots) { my_np = np; my_stored = stored; my_k = k; }
     }
+    __threadfence_block();
     __syncthreads();
+    CT_STAMP(4);
     // ---- 4. the winner's points, hull, rectangle ------------------------------------------------------------------------------
     const unsigned long long best = s_best;
     const int np_best = (int)(best >> 32);
-    int32_t* out = p.pts + (size_t)mi * p.max_pts * 2;
     if (np_best > p.max_pts || np_best <= 0) {
         if (tid == 0) { p.count[mi] = np_best > 0 ? -2 : 0; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
         return;
     }
-    if (tid == 0) {
-        const int lin = (int)(~(unsigned)(best & 0xffffffffull));
+    {
+        const int lin = (int)(0x7fffffffu - (unsigned)((best & 0xffffffffull) >> 1));
+        const int rot = (int)(best & 1ull);                      // 1: the start point is point 0 of the list
         const int sy = lin / bw, sx = lin - sy * bw;
-        int np = moore_trace<true>(bm, bw, sy, sx, max_steps, out, p.max_pts, bx0, by0);
-        if (np < 0) {                         // point 0 was appended last: rotate the list right by one so that it leads, as _compress orders it
-            np = -np;
-            const int lx = out[2 * (np - 1)], ly = out[2 * (np - 1) + 1];
-            for (int i = np - 1; i > 0; --i) { out[2 * i] = out[2 * (i - 1)]; out[2 * i + 1] = out[2 * (i - 1) + 1]; }
-            out[0] = lx; out[1] = ly;
+        if (my_k >= 0 && cand[my_k] == lin && my_np == np_best && my_stored <= slot_cap && np_best <= slot_cap) { s_win_slot = my_k; s_win_stored = my_stored; }
+        __syncthreads();
+        const int slot = s_win_slot;
+        if (slot >= 0) {                                         // every thread copies: the list is rot + stored points long
+            const int32_t* sp = out + (size_t)(slot + 1) * slot_cap * 2;
+            for (int j = tid; j < 2 * s_win_stored; j += CT_THREADS) out[2 * rot + j] = sp[j];
+            if (tid == 0 && rot) { out[0] = sx + bx0; out[1] = sy + by0; }
+        } else if (tid == 0) {                                   // no slot, or a list longer than one: trace once more, straight into the head
+            int kept0 = 0, stored = 0;
+            moore_trace<true>(bm, bw, sy, sx, max_steps, out + 2 * rot, p.max_pts - rot, bx0, by0, &kept0, &stored);
+            if (rot) { out[0] = sx + bx0; out[1] = sy + by0; }
         }
-        p.count[mi] = np;
-        s_np = np;
+        if (tid == 0) {
+            p.count[mi] = np_best;
+            s_np = np_best;
+            if (blockIdx.x == 0) g_ct_clk[9] = (unsigned long long)np_best;
+        }
         __threadfence_block();
     }
     __syncthreads();                          // (the bit image is dead from here on: its LDS becomes the hull's tables)
+    CT_STAMP(5);
     if (!p.rect) return;
     const int np = s_np;
     int* colmin = (int*)smem;
@@ -327,11 +386,16 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
             if (s_area[k] < barea || (s_area[k] == barea && s_idx[k] < bidx)) { barea = s_area[k]; bwid = s_w[k]; bhei = s_h[k]; bidx = s_idx[k]; }
         p.rect[2 * mi] = fmax(bwid, bhei); p.rect[2 * mi + 1] = fmin(bwid, bhei);
     }
+    CT_STAMP(6);
 }
+
+hipError_t contour_read_clocks(unsigned long long* out12) { return hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_ct_clk), 12 * sizeof(unsigned long long)); }
 
 hipError_t launch_contours(const uint8_t* masks, int n, int H, int W, int max_pts, int32_t* pts, int32_t* count, double* rect, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    ContourParams p{masks, n, H, W, max_pts, pts, count, rect};
+    ContourParams p{masks, n, H, W, max_pts, pts, count, rect, 0};
+    p.boxg = max_pts / 2 < CT_BOXG ? max_pts / 2 : CT_BOXG;      // a partial box takes two points' worth of the list
+    if (p.boxg < 1) return hipErrorInvalidValue;
     const size_t sh = (size_t)CT_BITMAP_BYTES + (size_t)CT_MAXCAND * sizeof(int);
     static bool attr = false;
     if (!attr) {
@@ -339,6 +403,7 @@ hipError_t launch_contours(const uint8_t* masks, int n, int H, int W, int max_pt
         if (e != hipSuccess) return e;
         attr = true;
     }
+    hipLaunchKernelGGL(contour_bbox_kernel, dim3(p.boxg, n), dim3(256), 0, st, p);
     hipLaunchKernelGGL(contour_kernel, dim3(n), dim3(CT_THREADS), sh, st, p);
     return hipGetLastError();
 }

@@ -1805,7 +1805,7 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
 }
 
 int yp_mask_contours(const uint8_t* masks_dev, int n, int H, int W, int max_pts, int32_t* pts_out, int32_t* count_out, double* rect_out, void* stream) {
-    if (n < 0 || H <= 0 || W <= 0 || max_pts <= 0) return fail(YP_ERR_ARG, "yp_mask_contours: bad sizes");
+    if (n < 0 || H <= 0 || W <= 0 || max_pts < 2) return fail(YP_ERR_ARG, "yp_mask_contours: bad sizes (max_pts >= 2)");
     if (n > 0 && (!masks_dev || !pts_out || !count_out)) return fail(YP_ERR_ARG, "yp_mask_contours: null buffer");
     if ((long)H * W >= (1l << 31)) return fail(YP_ERR_ARG, "yp_mask_contours: image too large");
     HIPCHK(launch_contours(masks_dev, n, H, W, max_pts, pts_out, count_out, rect_out, (hipStream_t)stream));
@@ -1827,6 +1827,13 @@ int yp_debug_head_clocks(uint64_t* out8) {
     if (!out8) return fail(YP_ERR_ARG, "yp_debug_head_clocks: null output");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(head_read_clocks((unsigned long long*)out8));
+    return YP_OK;
+}
+
+int yp_debug_contour_clocks(uint64_t* out12) {
+    if (!out12) return fail(YP_ERR_ARG, "yp_debug_contour_clocks: null output");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(contour_read_clocks((unsigned long long*)out12));
     return YP_OK;
 }
 

@@ -9,6 +9,7 @@ import ctypes as C
 import os
 from typing import Dict, List, Optional, Tuple
 
+import numpy as np
 import torch
 
 from .weights import fold_state
@@ -74,6 +75,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_debug_force_conv_cfg.argtypes = [C.c_int]
     lib.yp_debug_ablation.argtypes = [C.c_int]
     lib.yp_debug_head_clocks.argtypes = [C.POINTER(C.c_uint64)]
+    lib.yp_debug_contour_clocks.argtypes = [C.POINTER(C.c_uint64)]
     lib.yp_letterbox.argtypes = [vp, C.c_int, C.c_int, vp] + [C.c_int] * 7 + [vp]
     lib.yp_letterbox.restype = C.c_int
     lib.yp_comm_unique_id.argtypes = [vp]
@@ -95,7 +97,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
+           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_contour_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy",
            "yp_u2net_create", "yp_u2net_destroy", "yp_u2net_weight_count", "yp_u2net_weight_info", "yp_u2net_set_weight", "yp_u2net_finalize",
            "yp_u2net_forward", "yp_u2net_set_graph", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
@@ -125,28 +127,48 @@ def letterbox_device(src: torch.Tensor, geo: dict, out: Optional[torch.Tensor] =
     return out
 
 
-def mask_contours_device(masks: torch.Tensor, max_pts: int = 16384, want_rect: bool = True):
+def mask_contours_device(masks: torch.Tensor, max_pts: Optional[int] = None, want_rect: bool = True):
     """yp_mask_contours: uint8 cuda [n,H,W] -> (list of int32 [m,2] numpy polygons (None where the device path declined), rect float64 [n,2]
-    numpy (long side, short side) or None). One small D2H of the points; the masks stay on the device."""
+    numpy (long side, short side) or None). The masks stay on the device; counts, rectangles and the heads of the point lists share one
+    allocation so that a single mask (what the reference's loop asks for per frame) costs ONE device-to-host copy. `max_pts` also sizes
+    the kernel's per-candidate lists (1024 points each behind the result): the default is generous for one mask, 16384 per mask otherwise."""
     if not (masks.is_cuda and masks.dtype == torch.uint8 and masks.dim() == 3):
         raise ValueError("mask_contours_device needs a uint8 CUDA tensor [n,H,W]")
     masks = masks.contiguous()
     n, H, W = (int(v) for v in masks.shape)
+    if max_pts is None:
+        max_pts = 131072 if n <= 2 else 16384
     dev = masks.device
-    pts = torch.empty((n, max_pts, 2), dtype=torch.int32, device=dev)
-    cnt = torch.empty((n,), dtype=torch.int32, device=dev)
-    rect = torch.empty((n, 2), dtype=torch.float64, device=dev) if want_rect else None
+    # int32 words: [count (n) | pad | rect (n x 2 float64) | points (n x max_pts x 2)]
+    o_rect = (n + 1) // 2 * 2
+    o_pts = o_rect + 4 * n
+    buf = torch.empty((o_pts + n * max_pts * 2,), dtype=torch.int32, device=dev)
     lib = load_library()
     with torch.cuda.device(dev):
-        rc = lib.yp_mask_contours(C.c_void_p(masks.data_ptr()), n, H, W, int(max_pts), C.c_void_p(pts.data_ptr()), C.c_void_p(cnt.data_ptr()),
-                                  C.c_void_p(rect.data_ptr() if rect is not None else None), C.c_void_p(_stream_ptr(dev)))
+        base = buf.data_ptr()
+        rc = lib.yp_mask_contours(C.c_void_p(masks.data_ptr()), n, H, W, int(max_pts), C.c_void_p(base + 4 * o_pts), C.c_void_p(base),
+                                  C.c_void_p(base + 4 * o_rect if want_rect else None), C.c_void_p(_stream_ptr(dev)))
     if rc != 0:
         raise YolopError(lib.yp_last_error().decode())
-    c = cnt.cpu().numpy()
-    top = int(max(1, c.max())) if n else 1
-    host = pts[:, :top].cpu().numpy()
+    if n == 0:
+        return [], (np.zeros((0, 2)) if want_rect else None)
+    head_pts = min(max_pts, 1024)
+    if n == 1:
+        h = buf[:o_pts + 2 * head_pts].cpu().numpy()
+        c = h[:1]
+        rect = h[o_rect:o_rect + 4].view(np.float64).reshape(1, 2).copy() if want_rect else None
+        if c[0] > head_pts:
+            host = buf[o_pts:o_pts + 2 * int(c[0])].cpu().numpy().reshape(1, -1, 2)
+        else:
+            host = h[o_pts:].reshape(1, -1, 2)
+    else:
+        h = buf[:o_pts].cpu().numpy()
+        c = h[:n]
+        rect = h[o_rect:o_rect + 4 * n].view(np.float64).reshape(n, 2).copy() if want_rect else None
+        top = int(max(1, c.max()))
+        host = buf[o_pts:].view(n, max_pts, 2)[:, :top].cpu().numpy()
     polys = [host[i, :c[i]].copy() if c[i] >= 0 else None for i in range(n)]
-    return polys, (rect.cpu().numpy() if rect is not None else None)
+    return polys, rect
 
 
 class Engine:
