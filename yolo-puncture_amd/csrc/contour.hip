@@ -45,18 +45,18 @@ __device__ unsigned long long g_ct_clk[12];
 struct Bitmap {
     const unsigned* w;   // LDS
     int pitch;           // words per row
-    // 8-neighbour mask of pixel (y,x) in image-local coordinates (row y lives at y+1, column x at bit x+32)
-    __device__ __forceinline__ unsigned nb(int y, int x) const {
+    // 8-neighbour ring of the pixel in column x whose row ABOVE starts at word `rb` (row y of the image lives at stored row y + 1, column x
+    // at bit x + 32): bits E, SE, S, SW, W, NW, N, NE. Three 64-bit windows, one shift each; the row below arrives mirrored through a
+    // packed 3-bit reversal table.
+    __device__ __forceinline__ unsigned ring(int rb, int x) const {
         const int pos = x + 31;                              // bit position of x-1
-        const int j = pos >> 5, sh = pos & 31;
-        const unsigned* r0 = w + (size_t)y * pitch + j;      // row above (y-1 -> stored row y)
+        const unsigned* r0 = w + rb + (pos >> 5);
+        const int sh = pos & 31;
         const unsigned long long u = ((unsigned long long)r0[1] << 32) | r0[0];
         const unsigned long long m = ((unsigned long long)r0[pitch + 1] << 32) | r0[pitch];
         const unsigned long long d = ((unsigned long long)r0[2 * pitch + 1] << 32) | r0[2 * pitch];
         const unsigned uu = (unsigned)(u >> sh) & 7u, mm = (unsigned)(m >> sh) & 7u, dd = (unsigned)(d >> sh) & 7u;
-        // E, SE, S, SW, W, NW, N, NE
-        return ((mm >> 2) & 1u) | (((dd >> 2) & 1u) << 1) | (((dd >> 1) & 1u) << 2) | ((dd & 1u) << 3) | ((mm & 1u) << 4) | ((uu & 1u) << 5) |
-               (((uu >> 1) & 1u) << 6) | (((uu >> 2) & 1u) << 7);
+        return (mm >> 2) | ((0x73516240u >> (4 * dd)) & 7u) << 1 | (mm & 1u) << 4 | uu << 5;
     }
 };
 
@@ -73,23 +73,32 @@ constexpr int CT_BOXG = 32;                 // workgroups per mask of the boundi
 //   counting pass.
 template <bool EMIT>
 __device__ int moore_trace(const Bitmap& bm, int bw, int sy, int sx, int max_steps, int32_t* out, int cap, int ox, int oy, int* start_kept, int* stored) {
+    // The step is the serial path of the whole kernel (one lane walks the winning border alone), so it carries as little as possible:
+    // running row base and linear index instead of multiplications, the first step peeled so that the loop has no "first time" tests,
+    // the pending point is always the current pixel.
     const int start_lin = sy * bw + sx;
-    int cy = sy, cx = sx, d = 6;                 // "arrived" from the north-west side: start searching at north
-    int start_d = -1, prev_move = -1, first_move = -1;
-    int npts = 1, nkeep = 0;
-    int px = sx, py = sy;                        // the point whose keep decision is pending: it is kept iff the moves before and after differ
+    int cy = sy, cx = sx, rb = sy * bm.pitch, lin = start_lin;
     *start_kept = 0;
     if (EMIT) *stored = 0;
-    for (int step = 0; step < max_steps; ++step) {
-        const unsigned nbm = bm.nb(cy, cx);
-        if (nbm == 0) {                           // isolated pixel
-            *start_kept = 1;
-            return 1;
-        }
-        const unsigned rot = ((nbm >> d) | (nbm << (8 - d))) & 0xffu;
-        const int nd = (d + __builtin_ctz(rot)) & 7;
-        if (start_d < 0) start_d = nd;
-        else if (cy == sy && cx == sx && nd == start_d) {
+    unsigned nbm = bm.ring(rb, cx);
+    if (nbm == 0) {                               // isolated pixel
+        *start_kept = 1;
+        return 1;
+    }
+    // first move: "arrived" from the north-west side, the search starts at north (d = 6)
+    int nd = (6 + __builtin_ctz(((nbm >> 6) | (nbm << 2)) & 0xffu)) & 7;
+    const int start_d = nd, first_move = nd;
+    int prev_move = nd, npts = 2, nkeep = 0;
+    {
+        const int dy = c_dy(nd), dx = c_dx(nd);
+        cy += dy; cx += dx; rb += dy * bm.pitch; lin += dy * bw + dx;
+    }
+    if (lin < start_lin) return 0;
+    int d = (nd + 6 - (nd & 1)) & 7;              // restart at the background pixel examined last
+    for (int step = 1; step < max_steps; ++step) {
+        nbm = bm.ring(rb, cx);                    // (never empty: the pixel we came from is a neighbour)
+        nd = (d + __builtin_ctz(((nbm >> d) | (nbm << (8 - d))) & 0xffu)) & 7;
+        if (lin == start_lin && nd == start_d) {
             // closed: pts[:-1] drops the repeated start, n = npts - 1 points, moves m_0..m_{n-1} (the last one returned to the start)
             const int n = npts - 1;
             if (n <= 2) {                         // _compress keeps everything: the start, then (n == 2) the pixel the first move leads to
@@ -108,18 +117,16 @@ __device__ int moore_trace(const Bitmap& bm, int bw, int sy, int sx, int max_ste
             }
             return nkeep > 0 ? nkeep : 1;         // (all moves equal cannot happen on a closed trace; _compress would keep pts[0])
         }
-        // take the move
-        if (first_move < 0) first_move = nd;
-        else if (nd != prev_move) {               // the point we are leaving (px,py) had a different move before it: kept
-            if (EMIT && nkeep < cap) { out[2 * nkeep] = px + ox; out[2 * nkeep + 1] = py + oy; }
+        if (nd != prev_move) {                    // the pixel we are leaving had a different move before it: kept
+            if (EMIT && nkeep < cap) { out[2 * nkeep] = cx + ox; out[2 * nkeep + 1] = cy + oy; }
             ++nkeep;
         }
         prev_move = nd;
-        cy += c_dy(nd); cx += c_dx(nd);
-        px = cx; py = cy;
+        const int dy = c_dy(nd), dx = c_dx(nd);
+        cy += dy; cx += dx; rb += dy * bm.pitch; lin += dy * bw + dx;
         ++npts;
-        if (cy * bw + cx < start_lin) return 0;  // not the raster-first pixel of its blob's outer border
-        d = (nd & 1) ? ((nd + 5) & 7) : ((nd + 6) & 7);   // restart at the background pixel examined last
+        if (lin < start_lin) return 0;            // not the raster-first pixel of its blob's outer border
+        d = (nd + 6 - (nd & 1)) & 7;
     }
     return 0;
 }
@@ -293,8 +300,8 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     const int np = s_np;
     int* colmin = (int*)smem;
     int* colmax = colmin + CT_MAXCOL;
-    int* hull = colmax + CT_MAXCOL;           // up to 2 * CT_MAXCOL + 2 vertices, (x, y) interleaved
-    static_assert((size_t)(2 * CT_MAXCOL + 2 * (2 * CT_MAXCOL + 2)) * sizeof(int) <= (size_t)CT_BITMAP_BYTES, "hull tables fit the bit image's LDS");
+    int* hull = colmax + CT_MAXCOL;           // up to 2 * CT_MAXCOL + 2 vertices, (x, y) interleaved; behind it the two chains under construction
+    static_assert((size_t)(2 * CT_MAXCOL + 2 * (2 * CT_MAXCOL + 2) + 4 * (CT_MAXCOL + 2)) * sizeof(int) <= (size_t)CT_BITMAP_BYTES, "hull tables fit the bit image's LDS");
     for (int i = tid; i < bw; i += CT_THREADS) { colmin[i] = 0x7fffffff; colmax[i] = -1; }
     __syncthreads();
     for (int i = tid; i < np; i += CT_THREADS) {
@@ -303,44 +310,74 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
         atomicMax(&colmax[x], y);
     }
     __syncthreads();
+    // Andrew's monotone chain over (x, colmin[x]), (x, colmax[x]) in (x, y) order: lower chain left->right, upper chain right->left;
+    // pops on cross <= 0 (no collinear vertices) - the points of a column between its extremes are popped by the full algorithm
+    // too, so this is exactly hostops._convex_hull on the unique points. The two chains are independent stacks: lane 0 of wave 0
+    // builds the lower one while lane 0 of wave 1 builds the upper one (each keeps the top two vertices in registers), then
+    // hull = lower[:-1] + upper[:-1].
+    __shared__ int s_chain_n[2], s_nuniq, s_first[2], s_last[2];
+    int* const chain_lo = hull + 2 * (2 * CT_MAXCOL + 2);     // a chain holds at most one vertex per column + 2 while it is built
+    int* const chain_up = chain_lo + 2 * (CT_MAXCOL + 2);
     if (tid == 0) {
-        // Andrew's monotone chain over (x, colmin[x]), (x, colmax[x]) in (x, y) order: lower chain left->right, upper chain right->left;
-        // pops on cross <= 0 (no collinear vertices) - the points of a column between its extremes are popped by the full algorithm
-        // too, so this is exactly hostops._convex_hull on the unique points
-        int n = 0;
-        auto cross_le0 = [&](int ax, int ay, int bx, int by, int qx, int qy) {
-            return (long long)(bx - ax) * (qy - ay) - (long long)(by - ay) * (qx - ax) <= 0;
-        };
         int nuniq = 0, fx = 0, fy = 0, gx = 0, gy = 0;
-        for (int x = 0; x < bw; ++x)
-            if (colmax[x] >= 0) {
-                if (nuniq == 0) { fx = x; fy = colmin[x]; }
-                nuniq += (colmin[x] != colmax[x]) ? 2 : 1;
-                gx = x; gy = colmax[x];
+        for (int x = 0; x < bw; ++x) {
+            const int lo = colmin[x], hi = colmax[x];
+            if (hi >= 0) {
+                if (nuniq == 0) { fx = x; fy = lo; }
+                nuniq += (lo != hi) ? 2 : 1;
+                gx = x; gy = hi;
             }
-        if (nuniq <= 2) {
-            hull[0] = fx; hull[1] = fy; n = 1;
-            if (nuniq == 2) { hull[2] = gx; hull[3] = gy; n = 2; }
-        } else {
-            auto push = [&](int qx, int qy, int base) {
-                while (n - base >= 2 && cross_le0(hull[2 * (n - 2)], hull[2 * (n - 2) + 1], hull[2 * (n - 1)], hull[2 * (n - 1) + 1], qx, qy)) --n;
-                hull[2 * n] = qx; hull[2 * n + 1] = qy; ++n;
-            };
-            for (int x = 0; x < bw; ++x)
-                if (colmax[x] >= 0) {
-                    push(x, colmin[x], 0);
-                    if (colmax[x] != colmin[x]) push(x, colmax[x], 0);
-                }
-            --n;                                  // lo[:-1]
-            const int base = n;
-            for (int x = bw - 1; x >= 0; --x)
-                if (colmax[x] >= 0) {
-                    if (colmax[x] != colmin[x]) push(x, colmax[x], base);
-                    push(x, colmin[x], base);
-                }
-            --n;                                  // up[:-1]
         }
-        s_nhull = n;
+        s_nuniq = nuniq; s_first[0] = fx; s_first[1] = fy; s_last[0] = gx; s_last[1] = gy;
+    }
+    if (tid == 0 || tid == 64) {
+        const bool upper = tid == 64;
+        int* const st = upper ? chain_up : chain_lo;
+        int n = 0;
+        int ax = 0, ay = 0, bx = 0, by = 0;                   // st[n-2], st[n-1] (valid when n >= 2 / n >= 1)
+        auto push = [&](int qx, int qy) {
+            while (n >= 2 && (long long)(bx - ax) * (qy - ay) - (long long)(by - ay) * (qx - ax) <= 0) {
+                --n;                                           // pop: the new top is the old second, the new second comes from LDS
+                bx = ax; by = ay;
+                if (n >= 2) { ax = st[2 * (n - 2)]; ay = st[2 * (n - 2) + 1]; }
+            }
+            st[2 * n] = qx; st[2 * n + 1] = qy; ++n;
+            ax = bx; ay = by; bx = qx; by = qy;
+        };
+        if (!upper) {
+            for (int x = 0; x < bw; ++x) {
+                const int lo = colmin[x], hi = colmax[x];
+                if (hi >= 0) {
+                    push(x, lo);
+                    if (hi != lo) push(x, hi);
+                }
+            }
+        } else {
+            for (int x = bw - 1; x >= 0; --x) {
+                const int lo = colmin[x], hi = colmax[x];
+                if (hi >= 0) {
+                    if (hi != lo) push(x, hi);
+                    push(x, lo);
+                }
+            }
+        }
+        s_chain_n[upper ? 1 : 0] = n;
+    }
+    __syncthreads();
+    {
+        const int nuniq = s_nuniq;
+        if (nuniq <= 2) {
+            if (tid == 0) {
+                hull[0] = s_first[0]; hull[1] = s_first[1];
+                if (nuniq == 2) { hull[2] = s_last[0]; hull[3] = s_last[1]; }
+                s_nhull = nuniq < 2 ? 1 : 2;
+            }
+        } else {
+            const int nlo = s_chain_n[0] - 1, nup = s_chain_n[1] - 1;     // lo[:-1], up[:-1]
+            for (int i = tid; i < nlo; i += CT_THREADS) { hull[2 * i] = chain_lo[2 * i]; hull[2 * i + 1] = chain_lo[2 * i + 1]; }
+            for (int i = tid; i < nup; i += CT_THREADS) { hull[2 * (nlo + i)] = chain_up[2 * i]; hull[2 * (nlo + i) + 1] = chain_up[2 * i + 1]; }
+            if (tid == 0) s_nhull = nlo + nup;
+        }
     }
     __syncthreads();
     const int nh = s_nhull;
