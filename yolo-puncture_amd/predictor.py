@@ -379,23 +379,27 @@ class YOLO:
             eng.set_graph(gmin > 0 and len(idxs) >= gmin)
             out = eng.forward(batch, cache.get(okey))
             cache[okey] = out
-            det = out["det"]
+            # ONE device-to-host copy of the [B,300,6] rows ends the forward; the conf filter and scale_boxes are a few dozen floats of
+            # host arithmetic (a chain of tiny device ops with two boolean gathers - each a device sync - cost ~0.1 ms per frame).
+            # Both heads emit their rows best first, so the rows above `conf` are a prefix and the coefficients are sliced, not gathered.
+            det_host = out["det"][:len(idxs)].cpu()
             for bi, i in enumerate(idxs):
                 oh, ow = imgs[i].shape[:2]
-                d = det[bi]
-                keep = d[:, 4] > conf                                   # strict, A.6 step 2
-                d = d[keep][:max_det]
+                dh = det_host[bi]
+                keep = dh[:, 4] > conf                                  # strict, A.6 step 2
+                n = int(keep.sum())
+                prefix = bool(keep[:n].all())
+                d = (dh[:n] if prefix else dh[keep])[:max_det].clone()
                 n = int(d.shape[0])
                 boxes_in = d[:, :4].clone()                              # letterboxed-input pixels
-                d = d.clone()
                 d[:, :4] = hostops.scale_boxes_t((H, W), d[:, :4], (oh, ow))
                 masks = None
                 if self.seg and n > 0:
-                    cf = out["coeff"][bi][keep][:max_det]
+                    cf = out["coeff"][bi][:n] if prefix else out["coeff"][bi][keep.to(dev)][:max_det]
                     if retina_masks:
-                        m, _, _ = eng.masks(bi, cf, d[:, :4], (oh, ow), retina=True)
+                        m, _, _ = eng.masks(bi, cf, d[:, :4].to(dev, non_blocking=True), (oh, ow), retina=True)
                     else:
-                        m, _, _ = eng.masks(bi, cf, boxes_in, (H, W), retina=False)
+                        m, _, _ = eng.masks(bi, cf, boxes_in.to(dev, non_blocking=True), (H, W), retina=False)
                     masks = Masks(None, (oh, ow), u8=m)
                 out_by_index[i] = Results(imgs[i], Boxes(d, (oh, ow)), masks, self.names, paths[i])
         for i in range(len(imgs)):
@@ -431,16 +435,17 @@ class YOLO:
         if self.family != "v10":
             eng.set_nms(conf, 0.7)
         out = eng.forward(batch)
-        d = out["det"][0]
-        keep = d[:, 4] > conf
-        d = d[keep]
-        n = int(d.shape[0])
+        dh = out["det"][0].cpu()                                        # (one copy; see predict())
+        keep = dh[:, 4] > conf
+        n = int(keep.sum())
+        prefix = bool(keep[:n].all())
+        d = dh[:n] if prefix else dh[keep]
         if n == 0:
             z = torch.zeros(out_hw, dtype=torch.int64, device=dev)
             e = torch.zeros(0)
             return z, torch.zeros(0, dtype=torch.int32), e, e
-        boxes = hostops.scale_boxes_t((H, W), d[:, :4], (oh, ow))
-        cf = out["coeff"][0][keep]
+        boxes = hostops.scale_boxes_t((H, W), d[:, :4], (oh, ow)).to(dev, non_blocking=True)
+        cf = out["coeff"][0][:n] if prefix else out["coeff"][0][keep.to(dev)]
         if out_hw == (oh, ow):
             _, ids, kept = eng.masks(0, cf, boxes, (oh, ow), retina=True, want_masks=False, want_ids=True,
                                      suppress_small=suppress_small, min_area=min_area)
@@ -448,4 +453,4 @@ class YOLO:
             # the reference resizes each float mask to (h,w) (torchvision F.resize: antialiased bilinear), tests the float area and
             # thresholds at 0.5 (:71-79): one GPU pass (yp_id_mask_resized)
             ids, kept = eng.id_mask_resized(0, cf, boxes, (oh, ow), out_hw, suppress_small=suppress_small, min_area=min_area)
-        return ids, kept.cpu(), d[:, 4].cpu(), d[:, 5].cpu()
+        return ids, kept.cpu(), d[:, 4].clone(), d[:, 5].clone()
