@@ -117,10 +117,11 @@ def test_graph_replay_equals_eager(eng):
                 assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("small_max,dtype", [("0", "fp32"), ("1000000000", "fp32"), ("1000000000", "bf16")])
+@pytest.mark.parametrize("small_max,dtype", [("0", "fp32"), ("1000000000", "fp32"), ("2000", "fp32"), ("1000000000", "bf16")])
 def test_conv_kernel_choice_forced(small_max, dtype, monkeypatch):
-    """The engine times conv_igemm against the K-split small-map kernel (conv_small.hip) per layer; here each is forced for every
-    layer it can run (YOLOP_U2_SMALL_MAX, read at create) and held to the reference fixture: fp32 to the 1e-3 bound of the other
+    """The engine times conv_igemm, the K-split small-map kernel (conv_small.hip) and the halo-tile kernel for large maps
+    (conv_halo_f32.hip) per layer; here each is forced for every layer it can run (YOLOP_U2_SMALL_MAX, read at create: 0 = conv_igemm
+    everywhere, otherwise conv_small up to that many output pixels and the halo kernel above) and held to the reference fixture: fp32 to the 1e-3 bound of the other
     tests (both kernels are fp32 FMA chains, they differ in summation order only), bf16 to the bf16 mode's closeness bound."""
     monkeypatch.setenv("YOLOP_U2_SMALL_MAX", small_max)
     z = np.load(os.path.join(GOLD, "u2netp_b.npz"))

@@ -28,6 +28,25 @@ __global__ __launch_bounds__(512) void mfma_kernel(const float* seed, float* sin
     if (s[0] == 123.456f) sink[threadIdx.x] = s[1] + s[2] + s[3];
 }
 
+// fp32 matrix rate: v_mfma_f32_16x16x4_f32 back to back on eight accumulators (the U^2-Net parity mode's instruction)
+__global__ __launch_bounds__(512) void mfma_f32_kernel(const float* seed, float* sink, int iters) {
+    const int lane = threadIdx.x & 63;
+    const float a = seed[lane], b = seed[lane + 512];
+    f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0, c4 = c0, c5 = c0, c6 = c0, c7 = c0;
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c3, 0, 0, 0);
+        c4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c4, 0, 0, 0);
+        c5 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c5, 0, 0, 0);
+        c6 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c6, 0, 0, 0);
+        c7 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c7, 0, 0, 0);
+    }
+    const f32x4 s = c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7;
+    if (s[0] == 123.456f) sink[threadIdx.x] = s[1] + s[2] + s[3];
+}
+
 __global__ __launch_bounds__(256) void copy_kernel(const float4* __restrict__ src, float4* __restrict__ dst, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
@@ -56,6 +75,19 @@ int main() {
         }
         const double flop = 256.0 * waves * iters * 8 * (2.0 * 16 * 16 * 32);
         printf("bf16 mfma 16x16x32, %d waves/CU: %.1f TFLOP/s (%.3f ms)\n", waves, flop / best * 1e-9, best);
+    }
+    for (int waves : {4, 8}) {
+        const int iters = 20000;
+        hipLaunchKernelGGL(mfma_f32_kernel, dim3(256), dim3(waves * 64), 0, 0, seed, sink, 1000);
+        CHECK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int r = 0; r < 3; ++r) {
+            CHECK(hipEventRecord(e0)); hipLaunchKernelGGL(mfma_f32_kernel, dim3(256), dim3(waves * 64), 0, 0, seed, sink, iters); CHECK(hipEventRecord(e1));
+            CHECK(hipDeviceSynchronize());
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        const double flop = 256.0 * waves * iters * 8 * (2.0 * 16 * 16 * 4);
+        printf("fp32 mfma 16x16x4, %d waves/CU: %.1f TFLOP/s (%.3f ms)\n", waves, flop / best * 1e-9, best);
     }
     const size_t bytes = 1ull << 30;
     float4 *a, *b;

@@ -293,6 +293,9 @@ hipError_t launch_attention(const AttnParams& p, int dtype, hipStream_t st);
 // conv_small.hip: fp32 3x3 for small maps (four waves split K, operands straight from L2)
 bool conv_small_valid(const ConvParams& p, int dtype);
 hipError_t launch_conv_small(const ConvParams& p, int dtype, hipStream_t st);
+// conv_halo_f32.hip: fp32 3x3 for large maps (8 x 32 pixel tiles, halo patch + weights by LDS-DMA, 16-channel chunks)
+bool conv_halo_f32_valid(const ConvParams& p, int dtype);
+hipError_t launch_conv_halo_f32(const ConvParams& p, int dtype, hipStream_t st);
 hipError_t launch_head(const HeadParams& p, hipStream_t st);
 hipError_t launch_letterbox(const uint8_t* src, int h0, int w0, uint8_t* dst, int out_h, int out_w, int new_h, int new_w, int top,
                             int left, int pad, hipStream_t st);

@@ -65,7 +65,7 @@ struct U2Op {
     View in, out, res;
     int widx = -1, dil = 1, act = ACT_RELU;
     int impl = -1;         // convs: -1 = not yet chosen for this plan, 0 = conv_igemm, 1 = conv_small, 2 = conv_small taking the max pool in
-                           // front of it while loading (tuned in the plan's first pass)
+                           // front of it while loading, 3 = conv_halo_f32 (tuned in the plan's first pass)
     int pool_op = -1;      // convs: index of the pool op that produces this conv's input and feeds nothing else (graph pass)
     int consumer = -1;     // pools: index of that conv; the pool does not launch while the conv runs with impl 2
 };
@@ -484,6 +484,7 @@ static hipError_t run_u2_op(const yp_u2net& e, const U2Op& o, const uint8_t* img
     if (o.kind != U2_CONV) return e.dtype == DT_BF16 ? run_small<__bf16>(e, o, img, st) : run_small<float>(e, o, img, st);
     const int impl = o.impl >= 0 ? o.impl : 0;
     const ConvParams p = u2_conv_params(e, o, impl == 2);
+    if (impl == 3) return launch_conv_halo_f32(p, e.dtype, st);
     return impl >= 1 ? launch_conv_small(p, e.dtype, st) : launch_conv_igemm(p, e.dtype, st);
 }
 
@@ -491,21 +492,27 @@ static hipError_t run_u2_op(const yp_u2net& e, const U2Op& o, const uint8_t* img
 // run), the faster one is kept for this plan. An op rewrites the same output from the same inputs, so repeating it is harmless.
 static int u2_tune_op(yp_u2net& e, U2Op& o, hipStream_t st) {
     const ConvParams p = u2_conv_params(e, o);
-    if (!conv_small_valid(p, e.dtype)) { o.impl = 0; return YP_OK; }
+    const bool can_small = conv_small_valid(p, e.dtype), can_halo = conv_halo_f32_valid(p, e.dtype);
+    if (!can_small && !can_halo) { o.impl = 0; return YP_OK; }
     static const bool fuse_pool = [] { const char* s = getenv("YOLOP_U2_FUSE_POOL"); return !(s && s[0] == '0'); }();
-    const bool can_fuse = fuse_pool && o.pool_op >= 0 && conv_small_valid(u2_conv_params(e, o, true), e.dtype);
-    if (e.small_max >= 0) { o.impl = u2_default_impl(e, p) ? (can_fuse ? 2 : 1) : 0; return YP_OK; }
+    const bool can_fuse = can_small && fuse_pool && o.pool_op >= 0 && conv_small_valid(u2_conv_params(e, o, true), e.dtype);
+    if (e.small_max >= 0) {                              // forced (tests): conv_small up to small_max pixels, the halo kernel above it
+        o.impl = (can_small && u2_default_impl(e, p)) ? (can_fuse ? 2 : 1) : ((can_halo && e.small_max > 0) ? 3 : 0);
+        return YP_OK;
+    }
     hipEvent_t e0, e1;
     U2HIP(hipEventCreate(&e0));
     U2HIP(hipEventCreate(&e1));
-    float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};          // igemm, small, small + pool, the pool launch alone
-    for (int v = 0; v < 4; ++v) {
-        if ((v == 2 || v == 3) && !can_fuse) continue;
+    // variants: 0 igemm, 1 small, 2 small + pool, 3 halo_f32, 4 = the pool launch alone (added to the unfused variants when comparing)
+    float best[5] = {1e30f, 1e30f, 1e30f, 1e30f, 1e30f};
+    for (int v = 0; v < 5; ++v) {
+        if ((v == 1 && !can_small) || ((v == 2 || v == 4) && !can_fuse) || (v == 3 && !can_halo)) continue;
         const ConvParams pv = u2_conv_params(e, o, v == 2);
         for (int rep = 0; rep < 4; ++rep) {              // rep 0 warms (code object, caches)
             U2HIP(hipEventRecord(e0, st));
             hipError_t err;
-            if (v == 3) err = e.dtype == DT_BF16 ? run_small<__bf16>(e, e.ops[o.pool_op], nullptr, st) : run_small<float>(e, e.ops[o.pool_op], nullptr, st);
+            if (v == 4) err = e.dtype == DT_BF16 ? run_small<__bf16>(e, e.ops[o.pool_op], nullptr, st) : run_small<float>(e, e.ops[o.pool_op], nullptr, st);
+            else if (v == 3) err = launch_conv_halo_f32(pv, e.dtype, st);
             else err = v >= 1 ? launch_conv_small(pv, e.dtype, st) : launch_conv_igemm(pv, e.dtype, st);
             if (err != hipSuccess) return u2fail(YP_ERR_HIP, "tuning launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
             U2HIP(hipEventRecord(e1, st));
@@ -517,12 +524,14 @@ static int u2_tune_op(yp_u2net& e, U2Op& o, hipStream_t st) {
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    o.impl = best[1] < best[0] ? 1 : 0;
-    if (can_fuse && best[2] < best[o.impl] + best[3]) o.impl = 2;
-    static const char* names[3] = {"igemm", "small", "small+pool"};
-    if (getenv("YOLOP_U2_TUNE_LOG")) fprintf(stderr, "[u2 tune] %-28s M %7d Cin %3d Cout %2d dil %d: igemm %.1f us, small %.1f us, small+pool %.1f us (pool alone %.1f us) -> %s\n",
-                                             o.name.c_str(), p.M, p.Cin, p.Cout, p.dil, best[0] * 1e3f, best[1] * 1e3f, can_fuse ? best[2] * 1e3f : 0.f,
-                                             can_fuse ? best[3] * 1e3f : 0.f, names[o.impl]);
+    o.impl = 0;
+    if (best[1] < best[o.impl]) o.impl = 1;
+    if (best[3] < best[o.impl]) o.impl = 3;
+    if (can_fuse && best[2] < best[o.impl] + best[4]) o.impl = 2;
+    static const char* names[4] = {"igemm", "small", "small+pool", "halo_f32"};
+    if (getenv("YOLOP_U2_TUNE_LOG")) fprintf(stderr, "[u2 tune] %-28s M %7d Cin %3d Cout %2d dil %d: igemm %.1f us, small %.1f us, small+pool %.1f us (pool alone %.1f us), halo_f32 %.1f us -> %s\n",
+                                             o.name.c_str(), p.M, p.Cin, p.Cout, p.dil, best[0] * 1e3f, can_small ? best[1] * 1e3f : 0.f, can_fuse ? best[2] * 1e3f : 0.f,
+                                             can_fuse ? best[4] * 1e3f : 0.f, can_halo ? best[3] * 1e3f : 0.f, names[o.impl]);
     return YP_OK;
 }
 
