@@ -117,6 +117,8 @@ struct ConvParams {
     // conv_small only: x is the tensor IN FRONT OF a 2x2 / stride-2 / ceil-mode max pool (src_H x src_W pixels) and the pool is taken
     // while loading; H, W stay the pooled size the convolution sees
     int pool_in, src_H, src_W;
+    // conv_small only: the x2 channels are a BILINEAR resize (align_corners = False) of x2 to H x W instead of the nearest x2 above
+    int up_bilinear;
 };
 
 struct DwParams {

@@ -35,6 +35,11 @@ template <> struct CsT<float> {
     typedef float4 Vec;
     static __device__ __forceinline__ Vec zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
     static __device__ __forceinline__ Vec vmax(const Vec& a, const Vec& b) { return make_float4(fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)); }
+    // bilinear tap, the expression of u2_up_kernel (u2net.hip)
+    static __device__ __forceinline__ Vec lerp(const Vec& a, const Vec& b, const Vec& c, const Vec& d, float ly0, float ly1, float lx0, float lx1) {
+        return make_float4(ly0 * (lx0 * a.x + lx1 * b.x) + ly1 * (lx0 * c.x + lx1 * d.x), ly0 * (lx0 * a.y + lx1 * b.y) + ly1 * (lx0 * c.y + lx1 * d.y),
+                           ly0 * (lx0 * a.z + lx1 * b.z) + ly1 * (lx0 * c.z + lx1 * d.z), ly0 * (lx0 * a.w + lx1 * b.w) + ly1 * (lx0 * c.w + lx1 * d.w));
+    }
     static __device__ __forceinline__ void mma(cs_f32x4& acc, const Vec& w, const Vec& x) {
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, acc, 0, 0, 0);
@@ -50,6 +55,16 @@ template <> struct CsT<__bf16> {
         return (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
     }
     static __device__ __forceinline__ Vec vmax(const Vec& a, const Vec& b) { return make_uint2(max2(a.x, b.x), max2(a.y, b.y)); }
+    static __device__ __forceinline__ unsigned lerp2(unsigned a, unsigned b, unsigned c, unsigned d, float ly0, float ly1, float lx0, float lx1) {
+        const float lo = ly0 * (lx0 * __uint_as_float(a << 16) + lx1 * __uint_as_float(b << 16)) + ly1 * (lx0 * __uint_as_float(c << 16) + lx1 * __uint_as_float(d << 16));
+        const float hi = ly0 * (lx0 * __uint_as_float(a & 0xffff0000u) + lx1 * __uint_as_float(b & 0xffff0000u)) +
+                         ly1 * (lx0 * __uint_as_float(c & 0xffff0000u) + lx1 * __uint_as_float(d & 0xffff0000u));
+        __attribute__((aligned(4))) __bf16 o[2] = {(__bf16)lo, (__bf16)hi};                 // (rounded as the stand-alone kernel stores it)
+        return *(const unsigned*)o;
+    }
+    static __device__ __forceinline__ Vec lerp(const Vec& a, const Vec& b, const Vec& c, const Vec& d, float ly0, float ly1, float lx0, float lx1) {
+        return make_uint2(lerp2(a.x, b.x, c.x, d.x, ly0, ly1, lx0, lx1), lerp2(a.y, b.y, c.y, d.y, ly0, ly1, lx0, lx1));
+    }
     static __device__ __forceinline__ void mma(cs_f32x4& acc, const Vec& w, const Vec& x) {
         union { uint2 u; cs_bf16x4 v; } a, b;
         a.u = w; b.u = x;
@@ -57,8 +72,23 @@ template <> struct CsT<__bf16> {
     }
 };
 
-template <typename T, int FN, int UB, bool POOL>
+// F.upsample(size=..., mode='bilinear') = upsample_bilinear2d, align_corners=False: src = scale*(dst+0.5)-0.5 clamped at 0 (as u2net.hip u2_bil)
+__device__ __forceinline__ void cs_bil(int dst, int n_in, int n_out, int& i0, int& i1, float& l0, float& l1) {
+    const float scale = (float)n_in / (float)n_out;
+    float f = scale * ((float)dst + 0.5f) - 0.5f;
+    f = fmaxf(f, 0.f);
+    i0 = (int)f;
+    i1 = i0 + ((i0 < n_in - 1) ? 1 : 0);
+    l1 = f - (float)i0;
+    l0 = 1.f - l1;
+}
+
+// MODE 0: plain; 1: the 2x2 ceil-mode max pool in front of the convolution taken while loading; 2: input channels [0, x2_C) are the
+// bilinear resize of the low-resolution tensor x2 to the convolution's input size, taken while loading (the up-sample launch and its
+// half of the concat buffer disappear); channels >= x2_C come from x as usual
+template <typename T, int FN, int UB, int MODE>
 __global__ __launch_bounds__(256) void conv_small_kernel(const ConvParams p) {
+    constexpr bool POOL = MODE == 1, UP = MODE == 2;
     typedef typename CsT<T>::Vec Vec;
     __shared__ float4 part[4][FN][64];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -79,6 +109,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvParams p) {
     const int nch = p.Cin >> 4, units = p.ks * p.ks * nch;
     const T* xb = (const T*)p.x + p.x_coff + 4 * g;
     const T* wb = (const T*)p.w + (size_t)fr * p.Kpad + 4 * g;
+    const T* x2b = UP ? (const T*)p.x2 + p.x2_coff + 4 * g : nullptr;
+    const int up_units = UP ? p.x2_C >> 4 : 0, bimg = valid ? m / HoWo : 0;
 
     cs_f32x4 acc[FN];
 #pragma unroll
@@ -109,6 +141,15 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvParams p) {
                             if (right) v = CsT<T>::vmax(v, *(const Vec*)(q2 + p.x_stride));
                         }
                         xv[i] = v;
+                    } else if (UP && cc < up_units) {
+                        int ya, yb, xa, xc;
+                        float ly0, ly1, lx0, lx1;
+                        cs_bil(hi, p.x2_H, p.H, ya, yb, ly0, ly1);
+                        cs_bil(wi, p.x2_W, p.W, xa, xc, lx0, lx1);
+                        const T* q0 = x2b + (size_t)((bimg * p.x2_H + ya) * p.x2_W) * p.x2_stride + cc * 16;
+                        const T* q1 = x2b + (size_t)((bimg * p.x2_H + yb) * p.x2_W) * p.x2_stride + cc * 16;
+                        xv[i] = CsT<T>::lerp(*(const Vec*)(q0 + (size_t)xa * p.x2_stride), *(const Vec*)(q0 + (size_t)xc * p.x2_stride),
+                                             *(const Vec*)(q1 + (size_t)xa * p.x2_stride), *(const Vec*)(q1 + (size_t)xc * p.x2_stride), ly0, ly1, lx0, lx1);
                     } else {
                         xv[i] = *(const Vec*)(xb + (size_t)(pbase + hi * p.W + wi) * p.x_stride + cc * 16);
                     }
@@ -172,7 +213,8 @@ __global__ __launch_bounds__(256) void conv_small_kernel(const ConvParams p) {
 }
 
 bool conv_small_valid(const ConvParams& p, int dtype) {
-    if (p.up != 1 || p.x2_C > 0) return false;
+    if (p.up != 1) return false;
+    if (p.x2_C > 0 && (!p.up_bilinear || (p.x2_C & 15) || (p.x2_stride & 3) || (p.x2_coff & 3) || p.pool_in)) return false;
     if ((p.Cin & 15) || p.Cout > 64 || p.ks != 3) return false;
     if ((p.x_stride & 3) || (p.x_coff & 3) || (p.Kpad & 3)) return false;
     if (dtype == DT_F32 && p.out_f32) return false;
@@ -184,13 +226,17 @@ template <typename T>
 static hipError_t launch_conv_small_t(const ConvParams& p, hipStream_t st) {
     const dim3 grid((unsigned)((p.M + 15) / 16)), blk(256);
     if (p.pool_in) {
-        if (p.Cout <= 16) hipLaunchKernelGGL((conv_small_kernel<T, 1, 4, true>), grid, blk, 0, st, p);
-        else if (p.Cout <= 32) hipLaunchKernelGGL((conv_small_kernel<T, 2, 4, true>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((conv_small_kernel<T, 4, 3, true>), grid, blk, 0, st, p);
+        if (p.Cout <= 16) hipLaunchKernelGGL((conv_small_kernel<T, 1, 4, 1>), grid, blk, 0, st, p);
+        else if (p.Cout <= 32) hipLaunchKernelGGL((conv_small_kernel<T, 2, 4, 1>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((conv_small_kernel<T, 4, 3, 1>), grid, blk, 0, st, p);
+    } else if (p.x2_C > 0) {
+        if (p.Cout <= 16) hipLaunchKernelGGL((conv_small_kernel<T, 1, 4, 2>), grid, blk, 0, st, p);
+        else if (p.Cout <= 32) hipLaunchKernelGGL((conv_small_kernel<T, 2, 4, 2>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((conv_small_kernel<T, 4, 3, 2>), grid, blk, 0, st, p);
     } else {
-        if (p.Cout <= 16) hipLaunchKernelGGL((conv_small_kernel<T, 1, 4, false>), grid, blk, 0, st, p);
-        else if (p.Cout <= 32) hipLaunchKernelGGL((conv_small_kernel<T, 2, 4, false>), grid, blk, 0, st, p);
-        else hipLaunchKernelGGL((conv_small_kernel<T, 4, 3, false>), grid, blk, 0, st, p);
+        if (p.Cout <= 16) hipLaunchKernelGGL((conv_small_kernel<T, 1, 4, 0>), grid, blk, 0, st, p);
+        else if (p.Cout <= 32) hipLaunchKernelGGL((conv_small_kernel<T, 2, 4, 0>), grid, blk, 0, st, p);
+        else hipLaunchKernelGGL((conv_small_kernel<T, 4, 3, 0>), grid, blk, 0, st, p);
     }
     return hipGetLastError();
 }

@@ -64,10 +64,11 @@ struct U2Op {
     std::string name;
     View in, out, res;
     int widx = -1, dil = 1, act = ACT_RELU;
-    int impl = -1;         // convs: -1 = not yet chosen for this plan, 0 = conv_igemm, 1 = conv_small, 2 = conv_small taking the max pool in
-                           // front of it while loading, 3 = conv_halo_f32 (tuned in the plan's first pass)
+    int impl = -1;         // convs: -1 = not yet chosen for this plan, 0 = conv_igemm, 1 = conv_small, 2 = conv_small taking the max pool /
+                           // bilinear up-sample in front of it while loading, 3 = conv_halo_f32 (tuned in the plan's first pass)
     int pool_op = -1;      // convs: index of the pool op that produces this conv's input and feeds nothing else (graph pass)
-    int consumer = -1;     // pools: index of that conv; the pool does not launch while the conv runs with impl 2
+    int up_op = -1;        // convs: index of the bilinear up-sample op that produces the first channels of this conv's input (graph pass)
+    int consumer = -1;     // pools / up-samples: index of that conv; the op does not launch while the conv runs with impl 2
 };
 
 }  // namespace
@@ -250,6 +251,27 @@ static int build_u2net(yp_u2net& e) {
         if (c.kind != U2_CONV || c.in.t != t || c.in.coff != 0 || c.in.C != e.tensors[t].C || c.res.t == t) continue;
         if (e.ops[i].out.coff != 0 || e.ops[i].out.C != e.tensors[t].C) continue;
         c.pool_op = (int)i;
+        e.ops[i].consumer = conv;
+    }
+    // likewise a bilinear up-sample that fills the FIRST channels of a concat buffer whose only reader of those channels is a convolution
+    // over the whole buffer (the decoder convolutions of every RSU and the first convolution of every decoder stage)
+    for (size_t i = 0; i < e.ops.size(); ++i) {
+        if (e.ops[i].kind != U2_UP) continue;
+        const View uo = e.ops[i].out;
+        if (uo.coff != 0 || (uo.C & 15)) continue;
+        int readers = 0, conv = -1;
+        for (size_t j = 0; j < e.ops.size(); ++j) {
+            const U2Op& o = e.ops[j];
+            if (j == i) continue;
+            if (o.in.t == uo.t && o.in.coff < uo.C) { ++readers; conv = (int)j; }
+            if (o.res.t == uo.t && o.res.coff < uo.C) { ++readers; conv = -2; }
+        }
+        bool side = false;
+        for (int k = 0; k < 6; ++k) side = side || e.side_t[k] == uo.t;
+        if (readers != 1 || conv < (int)i || side) continue;
+        U2Op& c = e.ops[conv];
+        if (c.kind != U2_CONV || c.in.coff != 0 || c.in.C != e.tensors[uo.t].C || c.pool_op >= 0) continue;
+        c.up_op = (int)i;
         e.ops[i].consumer = conv;
     }
     return YP_OK;
@@ -464,11 +486,16 @@ static ConvParams u2_conv_params(const yp_u2net& e, const U2Op& o, bool fuse_poo
     p.out_f32 = (to.f32 && e.dtype == DT_BF16) ? 1 : 0;
     p.up = 1; p.cfg = -1;
     p.x_bytes = ti.bytes; p.w_bytes = w.mat_bytes; p.y_bytes = to.bytes;
-    if (fuse_pool) {                                   // read the pool's input instead; H, W stay the pooled size
+    if (fuse_pool && o.pool_op >= 0) {                 // read the pool's input instead; H, W stay the pooled size
         const U2Op& po = e.ops[o.pool_op];
         const U2Tensor& ts = e.tensors[po.in.t];
         p.x = ts.ptr; p.x_stride = ts.C; p.x_coff = po.in.coff; p.x_bytes = ts.bytes;
         p.pool_in = 1; p.src_H = ts.H; p.src_W = ts.W;
+    } else if (fuse_pool && o.up_op >= 0) {            // the first channels come from the up-sample's low-resolution input
+        const U2Op& uo = e.ops[o.up_op];
+        const U2Tensor& ts = e.tensors[uo.in.t];
+        p.x2 = ts.ptr; p.x2_bytes = ts.bytes; p.x2_stride = ts.C; p.x2_coff = uo.in.coff; p.x2_C = uo.out.C; p.x2_H = ts.H; p.x2_W = ts.W;
+        p.up_bilinear = 1;
     }
     return p;
 }
@@ -480,7 +507,7 @@ static int u2_default_impl(const yp_u2net& e, const ConvParams& p) {
 }
 
 static hipError_t run_u2_op(const yp_u2net& e, const U2Op& o, const uint8_t* img, hipStream_t st) {
-    if (o.kind == U2_POOL && o.consumer >= 0 && e.ops[o.consumer].impl == 2) return hipSuccess;      // taken by its consumer while loading
+    if ((o.kind == U2_POOL || o.kind == U2_UP) && o.consumer >= 0 && e.ops[o.consumer].impl == 2) return hipSuccess;   // taken by its consumer while loading
     if (o.kind != U2_CONV) return e.dtype == DT_BF16 ? run_small<__bf16>(e, o, img, st) : run_small<float>(e, o, img, st);
     const int impl = o.impl >= 0 ? o.impl : 0;
     const ConvParams p = u2_conv_params(e, o, impl == 2);
@@ -495,7 +522,8 @@ static int u2_tune_op(yp_u2net& e, U2Op& o, hipStream_t st) {
     const bool can_small = conv_small_valid(p, e.dtype), can_halo = conv_halo_f32_valid(p, e.dtype);
     if (!can_small && !can_halo) { o.impl = 0; return YP_OK; }
     static const bool fuse_pool = [] { const char* s = getenv("YOLOP_U2_FUSE_POOL"); return !(s && s[0] == '0'); }();
-    const bool can_fuse = can_small && fuse_pool && o.pool_op >= 0 && conv_small_valid(u2_conv_params(e, o, true), e.dtype);
+    const int pre_op = o.pool_op >= 0 ? o.pool_op : o.up_op;      // the pool / up-sample this conv could take while loading (at most one)
+    const bool can_fuse = can_small && fuse_pool && pre_op >= 0 && conv_small_valid(u2_conv_params(e, o, true), e.dtype);
     if (e.small_max >= 0) {                              // forced (tests): conv_small up to small_max pixels, the halo kernel above it
         o.impl = (can_small && u2_default_impl(e, p)) ? (can_fuse ? 2 : 1) : ((can_halo && e.small_max > 0) ? 3 : 0);
         return YP_OK;
@@ -511,7 +539,7 @@ static int u2_tune_op(yp_u2net& e, U2Op& o, hipStream_t st) {
         for (int rep = 0; rep < 4; ++rep) {              // rep 0 warms (code object, caches)
             U2HIP(hipEventRecord(e0, st));
             hipError_t err;
-            if (v == 4) err = e.dtype == DT_BF16 ? run_small<__bf16>(e, e.ops[o.pool_op], nullptr, st) : run_small<float>(e, e.ops[o.pool_op], nullptr, st);
+            if (v == 4) err = e.dtype == DT_BF16 ? run_small<__bf16>(e, e.ops[pre_op], nullptr, st) : run_small<float>(e, e.ops[pre_op], nullptr, st);
             else if (v == 3) err = launch_conv_halo_f32(pv, e.dtype, st);
             else err = v >= 1 ? launch_conv_small(pv, e.dtype, st) : launch_conv_igemm(pv, e.dtype, st);
             if (err != hipSuccess) return u2fail(YP_ERR_HIP, "tuning launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
@@ -528,8 +556,8 @@ static int u2_tune_op(yp_u2net& e, U2Op& o, hipStream_t st) {
     if (best[1] < best[o.impl]) o.impl = 1;
     if (best[3] < best[o.impl]) o.impl = 3;
     if (can_fuse && best[2] < best[o.impl] + best[4]) o.impl = 2;
-    static const char* names[4] = {"igemm", "small", "small+pool", "halo_f32"};
-    if (getenv("YOLOP_U2_TUNE_LOG")) fprintf(stderr, "[u2 tune] %-28s M %7d Cin %3d Cout %2d dil %d: igemm %.1f us, small %.1f us, small+pool %.1f us (pool alone %.1f us), halo_f32 %.1f us -> %s\n",
+    static const char* names[4] = {"igemm", "small", "small+pre", "halo_f32"};
+    if (getenv("YOLOP_U2_TUNE_LOG")) fprintf(stderr, "[u2 tune] %-28s M %7d Cin %3d Cout %2d dil %d: igemm %.1f us, small %.1f us, small+pool/up %.1f us (pool/up alone %.1f us), halo_f32 %.1f us -> %s\n",
                                              o.name.c_str(), p.M, p.Cin, p.Cout, p.dil, best[0] * 1e3f, can_small ? best[1] * 1e3f : 0.f, can_fuse ? best[2] * 1e3f : 0.f,
                                              can_fuse ? best[4] * 1e3f : 0.f, can_halo ? best[3] * 1e3f : 0.f, names[o.impl]);
     return YP_OK;
