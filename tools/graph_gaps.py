@@ -38,3 +38,13 @@ gaps.sort()
 import statistics
 print(f"gaps/step {len(gaps) / n:.1f}: median {statistics.median(gaps) / 1e3:.2f} us, mean {sum(gaps) / len(gaps) / 1e3:.2f} us, "
       f"p90 {gaps[int(len(gaps) * .9)] / 1e3:.2f} us, max {gaps[-1] / 1e3:.2f} us")
+
+# timeline of the last step: every kernel's start / end relative to the step's first kernel start (us) and how many kernels run beside it
+if len(sys.argv) > 3 and sys.argv[3] == "timeline":
+    a, b = ends[-2], ends[-1]
+    seg = rows[a + 1:b + 1]
+    t0 = seg[0][0]
+    for s, e, nm in seg:
+        conc = sum(1 for s2, e2, _ in seg if s2 < e and e2 > s) - 1
+        short = nm.replace("void yp::", "").replace("yp::", "")[:58]
+        print(f"{(s - t0) / 1e3:8.1f} -> {(e - t0) / 1e3:8.1f}  {(e - s) / 1e3:6.1f} us  beside {conc}  {short}")
