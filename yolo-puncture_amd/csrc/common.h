@@ -257,6 +257,11 @@ int conv_tile1_num_cfgs();
 bool conv_tile1_cfg_valid(const ConvParams& p, int c);
 const char* conv_tile1_kernel_name(int c);
 hipError_t launch_conv_tile1(const ConvParams& p, int c, hipStream_t st);
+// K-split kernel for small pixel counts (conv_ks.hip); ids offset by 900
+int conv_ks_num_cfgs();
+bool conv_ks_cfg_valid(const ConvParams& p, int c);
+const char* conv_ks_kernel_name(int c);
+hipError_t launch_conv_ks(const ConvParams& p, int c, hipStream_t st);
 // pixels-direct 1x1 kernel (conv_pxd.hip); ids offset by 800
 int conv_pxd_num_cfgs();
 bool conv_pxd_cfg_valid(const ConvParams& p, int c);

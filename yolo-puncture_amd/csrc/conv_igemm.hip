@@ -247,7 +247,7 @@ static int conv_tile_choice(const ConvParams& p) {
 static int halo_choice(const ConvParams& p, int dtype) {
     if (dtype != DT_BF16) return -1;
     if (p.x2_C > 0) {        // folded upsample: only the persistent LDS-DMA families implement the two-source gather
-        auto ok = [&](int c) { return c >= 800 ? conv_pxd_cfg_valid(p, c - 800) : (c >= 400 && c < 500 ? conv_dma_lc_cfg_valid(p, c - 400) : (c >= 300 && c < 400 && conv_dma_p_cfg_valid(p, c - 300))); };
+        auto ok = [&](int c) { return c >= 900 ? false : c >= 800 ? conv_pxd_cfg_valid(p, c - 800) : (c >= 400 && c < 500 ? conv_dma_lc_cfg_valid(p, c - 400) : (c >= 300 && c < 400 && conv_dma_p_cfg_valid(p, c - 300))); };
         const int f = conv_dma_forced_cfg();
         if (ok(f)) return f;
         if (ok(p.cfg)) return p.cfg;
@@ -256,6 +256,7 @@ static int halo_choice(const ConvParams& p, int dtype) {
         return -2;
     }
     auto valid = [&](int c) {
+        if (c >= 900) return conv_ks_cfg_valid(p, c - 900);
         if (c >= 800) return conv_pxd_cfg_valid(p, c - 800);
         if (c >= 700) return conv_wreg_cfg_valid(p, c - 700);
         if (c >= 600) return conv_tile1_cfg_valid(p, c - 600);
@@ -275,6 +276,7 @@ static int halo_choice(const ConvParams& p, int dtype) {
 
 const char* conv_kernel_name(const ConvParams& p, int dtype) {
     const int h = halo_choice(p, dtype);
+    if (h >= 900) return conv_ks_kernel_name(h - 900);
     if (h >= 800) return conv_pxd_kernel_name(h - 800);
     if (h >= 700) return conv_wreg_kernel_name(h - 700);
     if (h >= 600) return conv_tile1_kernel_name(h - 600);
@@ -320,6 +322,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, int dtype, hipStream_t st) {
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st) {
     const int h = halo_choice(p, dtype);
     if (p.x2_C > 0 && h < 300) return hipErrorInvalidValue;      // (the plan folds an upsample only when such a configuration exists)
+    if (h >= 900) return launch_conv_ks(p, h - 900, st);
     if (h >= 800) return launch_conv_pxd(p, h - 800, st);
     if (h >= 700) return launch_conv_wreg(p, h - 700, st);
     if (h >= 600) return launch_conv_tile1(p, h - 600, st);

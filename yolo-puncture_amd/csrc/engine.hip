@@ -1128,6 +1128,8 @@ static int autotune(yp_engine& e) {
             for (int c = 0; !no_wr && c < conv_wreg_num_cfgs(); ++c) if (conv_wreg_cfg_valid(p, c)) cands.push_back(700 + c);
             static const bool no_px = [] { const char* v = std::getenv("YOLOP_NO_PXD"); return v && *v == '1'; }();     // A/B switch
             for (int c = 0; !no_px && c < conv_pxd_num_cfgs(); ++c) if (conv_pxd_cfg_valid(p, c)) cands.push_back(800 + c);
+            static const bool no_ks = [] { const char* v = std::getenv("YOLOP_NO_KS"); return v && *v == '1'; }();     // A/B switch
+            for (int c = 0; !no_ks && c < conv_ks_num_cfgs(); ++c) if (conv_ks_cfg_valid(p, c)) cands.push_back(900 + c);
             for (int cc : cands) {
                 o.cfg = cc;
                 float tmin;
@@ -1219,7 +1221,7 @@ static DwPwParams dwpw_params(const yp_engine& e, const Op& c) {
 // the persistent conv kernels are additionally templated on <HAS_RES, OUT_F32>: make the reported symbol exact
 static void finish_kernel_names(yp_engine& e) {
     for (Op& o : e.ops) {
-        const bool lc = o.kernel.find("_lc_kernel<") != std::string::npos || o.kernel.find("_s2_kernel<") != std::string::npos || o.kernel.find("_tile1_kernel<") != std::string::npos || o.kernel.find("_wreg_kernel<") != std::string::npos || o.kernel.find("_pxd_kernel<") != std::string::npos;
+        const bool lc = o.kernel.find("_lc_kernel<") != std::string::npos || o.kernel.find("_s2_kernel<") != std::string::npos || o.kernel.find("_tile1_kernel<") != std::string::npos || o.kernel.find("_wreg_kernel<") != std::string::npos || o.kernel.find("_pxd_kernel<") != std::string::npos || o.kernel.find("_ks_kernel<") != std::string::npos;
         if ((o.kernel.find("_p_kernel<") == std::string::npos && !lc) || o.kernel.find(",false>") != std::string::npos || o.kernel.find(",true>") != std::string::npos) continue;
         const bool f32 = (o.kind == OP_CONV) && e.tensors[o.out.t].f32 && e.dtype == DT_BF16;
         const bool res = o.res.t >= 0;
