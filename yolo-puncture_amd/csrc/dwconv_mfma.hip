@@ -32,7 +32,7 @@ static inline int dwm_pitch(int W, int KS) {
     return P;
 }
 
-template <int KS>
+template <int KS, bool SPLIT>
 __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwParams p, const int P, const int x_instr) {
     constexpr unsigned OOB = 0x80000000u;
     constexpr int W_INSTR = (KS * KS + 15) / 16;
@@ -45,6 +45,7 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwParams p, cons
     const int fr = lane & 15, fc = lane >> 4;
     const int nchunk = p.C >> 5;
     const int c = blockIdx.x % nchunk, b = blockIdx.x / nchunk;
+    const int psplit = (int)gridDim.y, ps = (int)blockIdx.y;      // the map's patches are dealt out over gridDim.y workgroups (one frame: 16 would idle 240 CUs)
     const int pad = KS / 2, HP = p.H + KS - 1;
 
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwParams p, cons
     const int dch = (fr + 16 * (fc >> 1)) & ~1;
 
     const int PW = p.W >> 2, NP = PW * (p.H >> 2);
+    const int nslot = ((NP + psplit - 1) / psplit + 3) >> 2;      // patch slots a wave of this workgroup can have
     f32x4 acc[DWM_MAXP][2];
     {
         const float4 b0 = *(const float4*)(p.bias + c * 32 + fc * 4);
@@ -93,7 +95,8 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwParams p, cons
     int pbase[DWM_MAXP];                                // halo pixel of this lane's patch pixel at tap (0,0)
 #pragma unroll
     for (int i = 0; i < DWM_MAXP; ++i) {
-        const int pi = (wave + 4 * i < NP) ? wave + 4 * i : wave;     // a wave's surplus slots redo its first patch (discarded):
+        const int pj = (wave + 4 * i) * psplit + ps;
+        const int pi = (pj < NP) ? pj : ((wave * psplit + ps < NP) ? wave * psplit + ps : 0);     // a wave's surplus slots redo its first patch (discarded):
         const int pr = pi / PW, pcn = pi - pr * PW;                    // the tap loop stays branch-free and the scheduler can
         pbase[i] = (pr * 4 + (fr >> 2)) * P + pcn * 4 + (fr & 3);      // keep the LDS reads of the next patch in flight
     }
@@ -114,6 +117,7 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwParams p, cons
         }
 #pragma unroll
         for (int i = 0; i < DWM_MAXP; ++i) {
+            if (SPLIT && i >= nslot) break;                     // (workgroup-uniform: slots beyond this workgroup's share of the patches)
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
                 const int hp = pbase[i] + ky * P + kx;
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwParams p, cons
     __bf16* yb = (__bf16*)p.y + (size_t)b * p.H * p.W * p.y_stride + p.y_coff + c * 32 + fc * 4;
 #pragma unroll
     for (int i = 0; i < DWM_MAXP; ++i) {
-        const int pi = wave + 4 * i;
+        const int pi = (wave + 4 * i) * psplit + ps;
         if (pi < NP) {
             const int pr = pi / PW, pcn = pi - pr * PW;
             const int yy = pr * 4 + (fr >> 2), xx = pcn * 4 + (fr & 3);
@@ -161,14 +165,18 @@ bool dwconv_mfma_valid(const DwParams& p, int dtype) {
 hipError_t launch_dwconv_mfma(const DwParams& p, hipStream_t st) {
     int x_instr = 0;
     const size_t sh = dwm_lds(p, &x_instr);
-    auto kern = dwconv_mfma_kernel<7>;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void*)dwconv_mfma_kernel<7, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)dwconv_mfma_kernel<7, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)(p.B * (p.C / 32))), dim3(256), sh, st, p, dwm_pitch(p.W, p.ks), x_instr);
+    // few (image, channel block) pairs: split each map's patches over up to 4 workgroups (every one stages the whole map - it is L2-resident)
+    const int wgs = p.B * (p.C / 32);
+    const int psplit = wgs >= 256 ? 1 : wgs >= 128 ? 2 : 4;
+    if (psplit == 1) hipLaunchKernelGGL((dwconv_mfma_kernel<7, false>), dim3((unsigned)wgs, 1), dim3(256), sh, st, p, dwm_pitch(p.W, p.ks), x_instr);
+    else hipLaunchKernelGGL((dwconv_mfma_kernel<7, true>), dim3((unsigned)wgs, (unsigned)psplit), dim3(256), sh, st, p, dwm_pitch(p.W, p.ks), x_instr);
     return hipGetLastError();
 }
 

@@ -737,7 +737,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
             q.x_stride = e.tensors[o.in.t].C; q.x_coff = o.in.coff; q.y_stride = e.tensors[o.out.t].C; q.y_coff = o.out.coff;
             q.res = o.res.t >= 0 ? (const void*)1 : nullptr;
             q.x_bytes = (size_t)B * q.H * q.W * q.x_stride * 2;
-            if (dwconv_mfma_valid(q, e.dtype)) snprintf(buf, sizeof(buf), "dwconv_mfma_kernel<%d>", o.k);
+            if (dwconv_mfma_valid(q, e.dtype)) snprintf(buf, sizeof(buf), "dwconv_mfma_kernel<%d,%s>", o.k, B * (q.C / 32) >= 256 ? "false" : "true");
             else if (o.k == 3 && o.s == 1) snprintf(buf, sizeof(buf), "dwconv_row_kernel<%s,3,1,4>", t);
             else if (o.k == 3 && o.s == 2) snprintf(buf, sizeof(buf), "dwconv_row_kernel<%s,3,2,2>", t);
             else if (o.k == 7 && o.s == 1) snprintf(buf, sizeof(buf), "dwconv_row_kernel<%s,7,1,2>", t);
