@@ -130,3 +130,23 @@ def test_masks_xy_uses_the_device_path_and_matches_host():
     host2 = Masks(torch.from_numpy(ms).float(), (360, 480))
     for a, b in zip(dev2.xy, host2.xy):
         assert np.array_equal(a, b)
+
+
+def test_hole_border_with_local_tops_is_not_a_contour():
+    """The segmented trace treats every local top as a checkpoint, also those on a hole's border (spikes rising from the floor of a hole);
+    a border counts only from its raster-first PIXEL, which for a hole border is no local top - so the wiggly hole below must not beat the
+    plain outer border (4 corner points), exactly as the host restatement (outer borders only) has it. A second mask nests a blob with its
+    own spikes inside the hole."""
+    m = np.zeros((80, 120), np.uint8)
+    m[10:70, 10:110] = 1
+    m[20:60, 20:100] = 0                       # the hole
+    for x in range(24, 96, 4):                 # spikes from the hole's floor: tips are local tops (W, NW, N, NE clear)
+        m[40 + (x % 8):60, x] = 1
+    m2 = m.copy()
+    m2[28:36, 40:80] = 1                       # a blob inside the hole
+    m2[24:28, 44:76:4] = 1                     # ... with spikes of its own (outer-border local tops of the nested blob)
+    polys, rect = mask_contours_device(torch.from_numpy(np.stack([m, m2])).cuda())
+    for i, mm in enumerate((m, m2)):
+        want = hostops.largest_external_contour(mm.astype(bool))
+        assert polys[i] is not None and np.array_equal(polys[i], want), (i, len(polys[i]), len(want))
+    assert len(polys[0]) == 4

@@ -131,6 +131,51 @@ __device__ int moore_trace(const Bitmap& bm, int bw, int sy, int sx, int max_ste
     return 0;
 }
 
+// One SEGMENT of a border: from candidate start (sy,sx) up to the next candidate start on the same border (possibly itself).
+// Every candidate (local top: W, NW, N, NE clear) is a natural checkpoint of the borders it lies on: a walker that stands on such a pixel
+// and is about to take the move a fresh trace would take there (first set neighbour clockwise from north) is, from then on, that fresh
+// trace - the next state of a Moore walker depends on (pixel, move) only. So instead of one lane walking a whole border while the
+// later local tops of the same border re-walk most of it in vain, every candidate's lane walks only to the next checkpoint; the borders
+// are then the cycles of the `next` pointers, and CHAIN_APPROX_SIMPLE is decided inside a segment as before and at the joints from
+// (last move of one segment, first move of the next).
+struct SegInfo { int next_lin, nkeep, nmoves, first_move, last_move, min_lin; };
+template <bool EMIT>
+__device__ void trace_segment(const Bitmap& bm, const unsigned* cbm, int bw, int sy, int sx, int max_steps, int32_t* out, int cap, int ox, int oy, SegInfo& si) {
+    const int start_lin = sy * bw + sx;
+    int cy = sy, cx = sx, rb = sy * bm.pitch, lin = start_lin;
+    si.next_lin = -1; si.nkeep = 0; si.nmoves = 0; si.first_move = 0; si.last_move = 0; si.min_lin = start_lin;
+    int mn = start_lin;
+    unsigned nbm = bm.ring(rb, cx);
+    if (nbm == 0) { si.next_lin = start_lin; return; }          // isolated pixel: a border of its own, no moves
+    int nd = (6 + __builtin_ctz(((nbm >> 6) | (nbm << 2)) & 0xffu)) & 7;
+    si.first_move = nd;
+    int prev_move = nd, nkeep = 0, nmoves = 1;
+    {
+        const int dy = c_dy(nd), dx = c_dx(nd);
+        cy += dy; cx += dx; rb += dy * bm.pitch; lin += dy * bw + dx;
+    }
+    int d = (nd + 6 - (nd & 1)) & 7;
+    for (int step = 1; step < max_steps; ++step) {
+        nbm = bm.ring(rb, cx);
+        nd = (d + __builtin_ctz(((nbm >> d) | (nbm << (8 - d))) & 0xffu)) & 7;
+        mn = min(mn, lin);
+        const unsigned cw = cbm[rb + bm.pitch + 1 + (cx >> 5)];
+        if (((cw >> (cx & 31)) & 1u) && nd == ((6 + __builtin_ctz(((nbm >> 6) | (nbm << 2)) & 0xffu)) & 7)) {
+            si.next_lin = lin; si.nkeep = nkeep; si.nmoves = nmoves; si.last_move = prev_move; si.min_lin = mn;
+            return;
+        }
+        if (nd != prev_move) {
+            if (EMIT && nkeep < cap) { out[2 * nkeep] = cx + ox; out[2 * nkeep + 1] = cy + oy; }
+            ++nkeep;
+        }
+        prev_move = nd;
+        const int dy = c_dy(nd), dx = c_dx(nd);
+        cy += dy; cx += dx; rb += dy * bm.pitch; lin += dy * bw + dx;
+        ++nmoves;
+        d = (nd + 6 - (nd & 1)) & 7;
+    }
+}
+
 // Bounding-box pre-pass: CT_BOXG workgroups per mask, each over a contiguous 1/CT_BOXG of the pixels; the partial boxes go to the head
 // of the mask's `pts` region (consumed by contour_kernel before it writes anything there). One workgroup scanning a 1280x720 mask
 // alone took 93 us of the 600-us kernel.
@@ -250,8 +295,150 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     // the list's head (region 0) takes the result; regions 1 .. nslots behind it are the candidates' own lists
     const int slot_cap = p.max_pts >= 8 * CT_SLOT_PTS ? CT_SLOT_PTS : p.max_pts / 8;
     const int nslots = slot_cap >= 8 ? min(CT_MAXSLOTS, p.max_pts / slot_cap - 1) : 0;
+    // ---- 3a. segmented trace (see trace_segment): needs a second bit image (the candidate pixels) + per-candidate tables in LDS ----
+    constexpr int CT_SEGMAX = 1024;
+    const size_t bm_bytes = (((size_t)(bh + 2) * pitch * 4) + 15) & ~(size_t)15;
+    bool seg_done = false;
+    if (ncand <= CT_SEGMAX && nslots > 0 && 2 * bm_bytes + (size_t)CT_SEGMAX * 28 <= (size_t)CT_BITMAP_BYTES) {
+        __shared__ int s_cyc_len, s_seg_ok;
+        unsigned* cbm = (unsigned*)(smem + bm_bytes);
+        int* nxt = (int*)(smem + 2 * bm_bytes);                  // successor candidate (index into the sorted list), -1 = none
+        int* nkp = nxt + CT_SEGMAX;                              // interior kept points of the segment
+        int* nmv = nkp + CT_SEGMAX;                              // moves of the segment (later: output offset of the segment's points)
+        int* mvs = nmv + CT_SEGMAX;                              // first move | last move << 4
+        int* cyc = mvs + CT_SEGMAX;                              // the winner's segments in border order
+        int* jkp = cyc + CT_SEGMAX;                              // winner: 1 if the joint point at the segment's start is kept
+        int* mnl = jkp + CT_SEGMAX;                              // raster-first pixel the segment visits
+        // sort the candidates by raster position (bitonic over the next power of two; pads = INT_MAX)
+        int n2 = 1;
+        while (n2 < ncand) n2 <<= 1;
+        for (int i = ncand + tid; i < n2; i += CT_THREADS) cand[i] = 0x7fffffff;
+        for (int i = tid; i < (int)(bm_bytes / 4); i += CT_THREADS) cbm[i] = 0u;
+        if (tid == 0) { s_cyc_len = 0; s_seg_ok = 1; }
+        __syncthreads();
+        for (int k2 = 2; k2 <= n2; k2 <<= 1)
+            for (int j = k2 >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < n2; i += CT_THREADS) {
+                    const int l = i ^ j;
+                    if (l > i) {
+                        const int a = cand[i], b = cand[l];
+                        if (((i & k2) == 0) ? (a > b) : (a < b)) { cand[i] = b; cand[l] = a; }
+                    }
+                }
+                __syncthreads();
+            }
+        for (int k = tid; k < ncand; k += CT_THREADS) {
+            const int lin = cand[k];
+            const int y = lin / bw, x = lin - y * bw;
+            atomicOr(&cbm[(size_t)(y + 1) * pitch + 1 + (x >> 5)], 1u << (x & 31));
+        }
+        __syncthreads();
+        auto find = [&](int lin) {                                // index of a candidate pixel in the sorted list
+            int lo = 0, hi = ncand - 1;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cand[mid] < lin) lo = mid + 1; else hi = mid; }
+            return cand[lo] == lin ? lo : -1;
+        };
+        for (int k = tid; k < ncand; k += CT_THREADS) {           // (ncand <= CT_THREADS: one segment per thread)
+            const int lin = cand[k];
+            const int sy = lin / bw, sx = lin - sy * bw;
+            SegInfo si;
+            if (k < nslots) trace_segment<true>(bm, cbm, bw, sy, sx, max_steps, out + (size_t)(k + 1) * slot_cap * 2, slot_cap, bx0, by0, si);
+            else trace_segment<false>(bm, cbm, bw, sy, sx, max_steps, nullptr, 0, bx0, by0, si);
+            nxt[k] = si.next_lin >= 0 ? find(si.next_lin) : -1;
+            nkp[k] = si.nkeep; nmv[k] = si.nmoves; mvs[k] = si.first_move | (si.last_move << 4); mnl[k] = si.min_lin;
+        }
+        __threadfence_block();
+        __syncthreads();
+        // borders = cycles of nxt; the raster-first candidate of a cycle leads it. Every candidate walks its cycle once.
+        for (int k = tid; k < ncand; k += CT_THREADS) {
+            int j = k, len = 0, kept = 0, moves = 0, lead = k, cmin = 0x7fffffff;
+            bool ok = true;
+            do {
+                const int jn = nxt[j];
+                if (jn < 0) { ok = false; break; }
+                cmin = min(cmin, mnl[j]);
+                kept += nkp[j] + (((mvs[j] >> 4) & 15) != (mvs[jn] & 15) ? 1 : 0);      // interior points + the joint point at jn
+                moves += nmv[j];
+                lead = min(lead, jn);
+                j = jn;
+            } while (j != k && ++len < ncand);
+            // a border counts from its raster-first PIXEL only (as the one-lane trace drops a walk that meets an earlier pixel): a hole
+            // border whose first pixel is no local top has candidates but no survivor
+            if (!ok || j != k || lead != k || cmin != cand[k]) continue;
+            const int pj = [&] { int q = k; while (nxt[q] != k) q = nxt[q]; return q; }();    // the segment that ends at the leader
+            const int start_kept = (((mvs[pj] >> 4) & 15) != (mvs[k] & 15)) ? 1 : 0;
+            int np;
+            if (moves == 0) np = 1;                                // isolated pixel
+            else if (moves <= 2) np = moves;                       // _compress keeps everything
+            else np = kept > 0 ? kept : 1;
+            const int sk = (moves <= 2) ? 1 : start_kept;
+            atomicMax(&s_best, ((unsigned long long)(unsigned)np << 32) | ((unsigned long long)(0x7fffffffu - (unsigned)cand[k]) << 1) | (unsigned)sk);
+        }
+        __syncthreads();
+        CT_STAMP(4);
+        const unsigned long long bestq = s_best;
+        const int npq = (int)(bestq >> 32);
+        if (npq > p.max_pts || npq <= 0) {
+            if (tid == 0) { p.count[mi] = npq > 0 ? -2 : 0; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
+            return;
+        }
+        const int linq = (int)(0x7fffffffu - (unsigned)((bestq & 0xffffffffull) >> 1));
+        const int rotq = (int)(bestq & 1ull);
+        if (tid == 0) {
+            // the winner's segments in order with the output offset of their points; anything that does not fit the lists -> serial trace
+            const int kb = find(linq);
+            int off = rotq, len = 0, j = kb, moves = 0;
+            bool ok = kb >= 0 && npq <= slot_cap;
+            while (ok) {
+                if (j >= nslots || nkp[j] > slot_cap) { ok = false; break; }
+                const int jn = nxt[j];
+                int joint = 0;
+                if (j != kb) {                                     // the joint point at this segment's start
+                    int q = cyc[len - 1];
+                    joint = (((mvs[q] >> 4) & 15) != (mvs[j] & 15)) ? 1 : 0;
+                }
+                jkp[j] = joint;
+                off += joint;
+                moves += nmv[j];
+                cyc[len++] = j;
+                const int myoff = off;
+                off += nkp[j];
+                nmv[j] = myoff;                                    // (moves are no longer needed: the slot becomes the offset)
+                j = jn;
+                if (j == kb) break;
+                if (len >= ncand) { ok = false; break; }
+            }
+            if (ok && (moves <= 2 || off != npq)) ok = false;      // tiny borders and any disagreement go the serial way
+            s_seg_ok = ok ? 1 : 0;
+            s_cyc_len = len;
+        }
+        __syncthreads();
+        const int sy = linq / bw, sx = linq - sy * bw;
+        if (s_seg_ok) {
+            const int len = s_cyc_len;
+            for (int i = wave; i < len; i += CT_THREADS / 64) {     // a wave per segment: joint point, then the segment's list
+                const int j = cyc[i];
+                const int o0 = nmv[j];
+                if (lane == 0 && jkp[j]) { const int l = cand[j]; const int yy = l / bw, xx = l - yy * bw; out[2 * (o0 - 1)] = xx + bx0; out[2 * (o0 - 1) + 1] = yy + by0; }
+                const int32_t* sp = out + (size_t)(j + 1) * slot_cap * 2;
+                for (int q = lane; q < 2 * nkp[j]; q += 64) out[2 * o0 + q] = sp[q];
+            }
+            if (tid == 0 && rotq) { out[0] = sx + bx0; out[1] = sy + by0; }
+        } else if (tid == 0) {
+            int kept0 = 0, stored = 0;
+            moore_trace<true>(bm, bw, sy, sx, max_steps, out + 2 * rotq, p.max_pts - rotq, bx0, by0, &kept0, &stored);
+            if (rotq) { out[0] = sx + bx0; out[1] = sy + by0; }
+        }
+        if (tid == 0) {
+            p.count[mi] = npq;
+            s_np = npq;
+            if (blockIdx.x == 0) g_ct_clk[9] = (unsigned long long)npq;
+        }
+        __threadfence_block();
+        seg_done = true;
+    }
     int my_np = 0, my_stored = 0, my_k = -1;                        // (a thread traces at most one candidate with a slot: slots < CT_THREADS)
-    for (int k = tid; k < ncand; k += CT_THREADS) {
+    for (int k = tid; !seg_done && k < ncand; k += CT_THREADS) {
         const int lin = cand[k];
         const int sy = lin / bw, sx = lin - sy * bw;
         int kept0 = 0, stored = 0, np;
@@ -263,15 +450,15 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     }
     __threadfence_block();
     __syncthreads();
-    CT_STAMP(4);
+    if (!seg_done) CT_STAMP(4);
     // ---- 4. the winner's points, hull, rectangle ------------------------------------------------------------------------------
     const unsigned long long best = s_best;
     const int np_best = (int)(best >> 32);
-    if (np_best > p.max_pts || np_best <= 0) {
+    if (!seg_done && (np_best > p.max_pts || np_best <= 0)) {
         if (tid == 0) { p.count[mi] = np_best > 0 ? -2 : 0; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
         return;
     }
-    {
+    if (!seg_done) {
         const int lin = (int)(0x7fffffffu - (unsigned)((best & 0xffffffffull) >> 1));
         const int rot = (int)(best & 1ull);                      // 1: the start point is point 0 of the list
         const int sy = lin / bw, sx = lin - sy * bw;
