@@ -2,16 +2,22 @@
 //     coord_xy = results[0].masks.xy[best]                 (yolo_seg/app.py:101; [U] masks2segments(strategy="largest") = cv2.findContours
 //                                                            RETR_EXTERNAL / CHAIN_APPROX_SIMPLE, the contour with the most points)
 //     rect_len, ratio = get_coord_min_rect_len(coord_xy)    (yolo_seg/app.py:102-103; yolo_seg/utils/mask_tools.py:12-22 = cv2.minAreaRect)
-// without the full-resolution mask ever leaving HBM. One workgroup per mask:
-//   1. bounding box of the set pixels (masks are zero outside their detection box), bit image of that box in LDS (one zero word / row around it)
+// without the full-resolution mask ever leaving HBM. A pre-pass finds the bounding boxes (32 workgroups per mask), then one workgroup per mask:
+//   1. bit image of the box in LDS (one zero word / row around it; masks are zero outside their detection box)
 //   2. candidate starts = set pixels whose W, NW, N, NE neighbours are clear (word-parallel bit logic). The raster-first pixel of every
-//      8-connected blob is one; other candidates sit on hole borders or are later local tops of a blob's outer border
-//   3. every candidate is Moore-traced by its own lane (3x3 neighbourhood = six LDS words fetched together, next direction by bit
-//      rotation + ctz; Jacob's stopping criterion). A trace that meets a pixel earlier in raster order than its start is not a blob's
-//      outer border from its first pixel and is dropped - no connected-component labelling is needed. The survivors are exactly the
-//      traces hostops.largest_external_contour makes; the one with the most CHAIN_APPROX_SIMPLE points wins (ties: first in raster order)
-//   4. the winner is traced once more, emitting the run end points; per-column min/max of those points -> Andrew's monotone chain on at
-//      most 2 points per column (exact integer cross products) -> rotating calipers over the hull edges in float64.
+//      8-connected blob is one; other candidates are later local tops of a blob's outer border or local tops on hole borders
+//   3. Moore traces (3x3 neighbourhood = three 64-bit LDS windows, next direction by bit rotation + ctz; Jacob's stopping criterion),
+//      CHAIN_APPROX_SIMPLE points written while walking into per-candidate lists inside the caller's point buffer:
+//      a. up to 1024 candidates: every candidate is a CHECKPOINT of its border, every lane walks only to the next one (trace_segment);
+//         borders = cycles of the `next` pointers, led by their raster-first candidate; a cycle whose raster-first pixel is not that
+//         candidate (a hole border) is dropped; point counts from the segments + the joints
+//      b. otherwise (noise masks): one lane per candidate walks its whole border; a walk that meets a pixel earlier in raster order than
+//         its start is not a blob's outer border from its first pixel and is dropped - no connected-component labelling either way.
+//      The survivors are exactly the traces hostops.largest_external_contour makes; the one with the most points wins (ties: first in
+//      raster order)
+//   4. the winner's list is assembled by parallel copies (a serial re-trace only when a list overflowed); per-column min/max of the points
+//      -> Andrew's monotone chain on at most 2 points per column (exact integer cross products, both chains at once) -> rotating calipers
+//      over the hull edges in float64.
 #include "common.h"
 #include <cstdio>
 
