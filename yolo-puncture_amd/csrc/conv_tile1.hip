@@ -116,14 +116,27 @@ __global__ __launch_bounds__(512) void conv_tile1_kernel(const ConvParams p, con
     const int npix = g.TR * g.TC;
     const int per_wave = (g.nfr + WGM - 1) / WGM;
     const int f0 = wm * per_wave;                                            // first fragment of this wave
-    int hbase[T1_FMX];
+    // LDS byte offset of this lane's 16-byte piece of pixel hp WITHOUT the swizzle: L = hp * 64 + fc * 16. The swizzle flips bit 5 where
+    // bit 2 of hp is set, and bit 2 of hp is bit 8 of L, so the address of any tap is (L + tap * 64) ^ (((L + tap * 64) >> 3) & 32): one add
+    // with a wave-uniform operand + two bit operations per fragment read. (Written as hp arithmetic the compiler spent ~9 VALU
+    // instructions per read - 86 per tap and wave, 2600 per wave against 504 MFMAs: PMC showed the VALU issuing 48 % of the kernel's
+    // cycles and the matrix pipe busy 30 %.)
+    unsigned lbase[T1_FMX];
 #pragma unroll
     for (int f = 0; f < T1_FMX; ++f) {
         int pp = (f0 + f) * 16 + fr;
         if (pp >= npix) pp = npix - 1;                                       // padding lanes read a valid pixel, never stored
         const int r = pp / g.TC, c = pp - r * g.TC;
-        hbase[f] = r * HC + c;
+        lbase[f] = (unsigned)((r * HC + c) * 64 + fc * 16);
     }
+    unsigned wl[3][FN];                                                      // the same for the weight rows of (kx, a) inside a ring stage
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int rw = kx * BN + wn * (FN * 16) + a * 16 + fr;
+            wl[kx][a] = (unsigned)(rw * 64 + ((fc ^ tswz(rw)) * 16));
+        }
     const int myf = max(0, min(per_wave, g.nfr - f0));                       // fragments that exist for this wave (wave-uniform)
 
     f32x4 acc[FN][T1_FMX];
@@ -146,19 +159,16 @@ __global__ __launch_bounds__(512) void conv_tile1_kernel(const ConvParams p, con
         const unsigned char* xs = Xs + (size_t)ch * g.ppc * 1024;
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const int tapoff = ky * HC + kx;
+            const unsigned tapb = (unsigned)((ky * HC + kx) * 64);
             bf16x8 wf[FN], xf[T1_FMX];
 #pragma unroll
-            for (int a = 0; a < FN; ++a) {
-                const int rw = kx * BN + wn * (FN * 16) + a * 16 + fr;
-                wf[a] = *(const bf16x8*)(ws + rw * 64 + ((fc ^ tswz(rw)) * 16));
-            }
+            for (int a = 0; a < FN; ++a) wf[a] = *(const bf16x8*)(ws + wl[kx][a]);
             // straight-line: every fragment read is issued before the first MFMA waits for one. Fragments beyond the wave's share
             // recompute a valid pixel and are never stored.
 #pragma unroll
             for (int f = 0; f < T1_FMX; ++f) {
-                const int hp = hbase[f] + tapoff;
-                xf[f] = *(const bf16x8*)(xs + hp * 64 + ((fc ^ tswz(hp)) * 16));
+                const unsigned L = lbase[f] + tapb;
+                xf[f] = *(const bf16x8*)(xs + (L ^ ((L >> 3) & 32u)));
             }
 #pragma unroll
             for (int f = 0; f < T1_FMX; ++f)
