@@ -131,8 +131,8 @@ __global__ __launch_bounds__(CF_NW * 64) void c2f_fused_kernel(const C2fParams p
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
         const int rw = tap * 32 + cf * 16 + fr;
-        wf1[tap] = *(const bf16x8*)(W1s + rw * 64 + ((fc ^ cswz(rw)) * 16));
-        wf2[tap] = *(const bf16x8*)(W2s + rw * 64 + ((fc ^ cswz(rw)) * 16));
+        wf1[tap] = *(const bf16x8*)(W1s + swz64((unsigned)(rw * 64 + fc * 16)));
+        wf2[tap] = *(const bf16x8*)(W2s + swz64((unsigned)(rw * 64 + fc * 16)));
     }
 
     unsigned long long clk[7] = {0, 0, 0, 0, 0, 0, 0};
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(CF_NW * 64) void c2f_fused_kernel(const C2fParams p
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int tp = (wq + 4 * j + tap / 3) * CF_TW + fr + tap % 3;
-                    xf[tap % (D + 1)][j] = *(const bf16x8*)(Ts + tp * 64 + ((fc ^ cswz(tp)) * 16));
+                    xf[tap % (D + 1)][j] = *(const bf16x8*)(Ts + swz64((unsigned)(tp * 64 + fc * 16)));
                 }
             };
             f32x4 acc[2];
@@ -255,14 +255,14 @@ __global__ __launch_bounds__(CF_NW * 64) void c2f_fused_kernel(const C2fParams p
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
-                for (int a = 0; a < 2; ++a) { const int rw = ch * 64 + (cf * 2 + a) * 16 + fr; wf3[ch][a] = *(const bf16x8*)(W3s + rw * 64 + ((fc ^ cswz(rw)) * 16)); }
+                for (int a = 0; a < 2; ++a) { const int rw = ch * 64 + (cf * 2 + a) * 16 + fr; wf3[ch][a] = *(const bf16x8*)(W3s + swz64((unsigned)(rw * 64 + fc * 16))); }
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int r = wq + 4 * j;
                 const int pp = (r + 2) * CF_PW + fr + 2, q = r * 16 + fr;
                 xf[j][0] = *(const bf16x8*)(AB + pp * 128 + ((fc ^ cswz128(pp)) * 16));
                 xf[j][1] = *(const bf16x8*)(AB + pp * 128 + (((4 + fc) ^ cswz128(pp)) * 16));
-                xf[j][2] = *(const bf16x8*)(Cs + q * 64 + ((fc ^ cswz(q)) * 16));
+                xf[j][2] = *(const bf16x8*)(Cs + swz64((unsigned)(q * 64 + fc * 16)));
             }
             f32x4 acc[2][2];
 #pragma unroll

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int hp = (RPW * wave + hy) * 18 + kx + fr;
-                const bf16x8 xf = *(const bf16x8*)(hsl + hp * 64 + ((fc ^ qswz(hp)) * 16));
+                const bf16x8 xf = *(const bf16x8*)(hsl + swz64((unsigned)(hp * 64 + fc * 16)));
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const int r = hy - ky;
@@ -248,12 +248,12 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
             const int rw = c * BN + wn * WN + a * 16 + fr;
-            wf[a] = *(const bf16x8*)(Wpw + rw * 64 + ((fc ^ qswz(rw)) * 16));
+            wf[a] = *(const bf16x8*)(Wpw + swz64((unsigned)(rw * 64 + fc * 16)));
         }
 #pragma unroll
         for (int b = 0; b < FM; ++b) {
             const int row = wm * WM + b * 16 + fr;
-            xf[b] = *(const bf16x8*)(asl + row * 64 + ((fc ^ qswz(row)) * 16));
+            xf[b] = *(const bf16x8*)(asl + swz64((unsigned)(row * 64 + fc * 16)));
         }
 #pragma unroll
         for (int a = 0; a < FN; ++a)

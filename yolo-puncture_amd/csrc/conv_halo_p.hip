@@ -166,12 +166,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_p_kernel(const ConvP
 #pragma unroll
                     for (int a = 0; a < FN; ++a) {
                         const int rw = (c * 9 + ky * 3 + kx) * BN + wn * (FN * 16) + a * 16 + fr;
-                        wf[ky][a] = *(const bf16x8*)(Wres + rw * 64 + ((fc ^ pswz(rw)) * 16));
+                        wf[ky][a] = *(const bf16x8*)(Wres + swz64((unsigned)(rw * 64 + fc * 16)));
                     }
 #pragma unroll
                 for (int hy = 0; hy < FM + 2; ++hy) {
                     const int hp = (wm * FM + hy) * 18 + kx + fr;
-                    const bf16x8 xf = *(const bf16x8*)(hsl + hp * 64 + ((fc ^ pswz(hp)) * 16));
+                    const bf16x8 xf = *(const bf16x8*)(hsl + swz64((unsigned)(hp * 64 + fc * 16)));
 #pragma unroll
                     for (int ky = 0; ky < 3; ++ky) {
                         const int r = hy - ky;

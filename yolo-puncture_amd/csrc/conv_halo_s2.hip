@@ -187,13 +187,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_halo_s2_kernel(const Conv
 #pragma unroll
                     for (int a = 0; a < FN; ++a) {
                         const int rw = (c * 9 + ky * 3 + kx) * BN + wn * (FN * 16) + a * 16 + fr;
-                        wf[ky][a] = *(const bf16x8*)(Wres + rw * 64 + ((fc ^ sswz(rw)) * 16));
+                        wf[ky][a] = *(const bf16x8*)(Wres + swz64((unsigned)(rw * 64 + fc * 16)));
                     }
                 const int eoff = (kx == 1) ? 17 + fr : fr + (kx >> 1);      // plane O at n, plane E at n / n+1
 #pragma unroll
                 for (int jj = 0; jj < 2 * FM + 1; ++jj) {
                     const int hp = (2 * wm * FM + jj) * 33 + eoff;
-                    const bf16x8 xf = *(const bf16x8*)(hsl + hp * 64 + ((fc ^ sswz(hp)) * 16));
+                    const bf16x8 xf = *(const bf16x8*)(hsl + swz64((unsigned)(hp * 64 + fc * 16)));
                     if (jj & 1) {
 #pragma unroll
                         for (int a = 0; a < FN; ++a)

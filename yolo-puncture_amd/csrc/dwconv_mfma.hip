@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwParams p, cons
 #pragma unroll
             for (int kx = 0; kx < KS; ++kx) {
                 const int hp = pbase[i] + ky * P + kx;
-                const bf16x8 xf = *(const bf16x8*)(Xs + hp * 64 + ((fc ^ mswz(hp)) * 16));
+                const bf16x8 xf = *(const bf16x8*)(Xs + swz64((unsigned)(hp * 64 + fc * 16)));
                 acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[kx][0], xf, acc[i][0], 0, 0, 0);
                 acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[kx][1], xf, acc[i][1], 0, 0, 0);
             }

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
 
     bf16x8 w0f[2];
 #pragma unroll
-    for (int h = 0; h < 2; ++h) { const int r = h * 16 + fr; w0f[h] = *(const bf16x8*)(W0s + r * 64 + ((fc ^ fswz(r)) * 16)); }
+    for (int h = 0; h < 2; ++h) { const int r = h * 16 + fr; w0f[h] = *(const bf16x8*)(W0s + swz64((unsigned)(r * 64 + fc * 16))); }
 
     unsigned long long clk[6] = {0, 0, 0, 0, 0, 0};
 #define FE_STAMP(i) if (p.clk) { const unsigned long long now = __builtin_amdgcn_s_memtime(); clk[i] += now - last; last = now; }
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
 #pragma unroll
             for (int j = 0; j < NF; ++j) {
                 const int hp = (f0 + j * FE_NW) * 16 + fr;
-                xf[j] = *(const bf16x8*)(Ib + hp * 64 + ((fc ^ fswz(hp)) * 16));
+                xf[j] = *(const bf16x8*)(Ib + swz64((unsigned)(hp * 64 + fc * 16)));
                 in[j] = Vs[hp] != 0;                      // else model.1's zero padding
             }
             f32x4 acc[NF][2];
@@ -254,13 +254,13 @@ __global__ __launch_bounds__(FE_NW * 64) void frontend_kernel(const FrontParams 
 #pragma unroll
                 for (int a = 0; a < FN; ++a) {
                     const int rw = (ky * 3 + kx) * BN + wn * (FN * 16) + a * 16 + fr;
-                    wf[ky][a] = *(const bf16x8*)(W1s + rw * 64 + ((fc ^ fswz(rw)) * 16));
+                    wf[ky][a] = *(const bf16x8*)(W1s + swz64((unsigned)(rw * 64 + fc * 16)));
                 }
             const int eoff = (kx == 1) ? 17 + fr : fr + (kx >> 1);
 #pragma unroll
             for (int jj = 0; jj < 2 * FM + 1; ++jj) {
                 const int hp = (2 * wm * FM + jj) * 33 + eoff;
-                const bf16x8 xf = *(const bf16x8*)(Hs + hp * 64 + ((fc ^ fswz(hp)) * 16));
+                const bf16x8 xf = *(const bf16x8*)(Hs + swz64((unsigned)(hp * 64 + fc * 16)));
                 if (jj & 1) {
 #pragma unroll
                     for (int a = 0; a < FN; ++a) acc[a][jj >> 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[1][a], xf, acc[a][jj >> 1], 0, 0, 0);
