@@ -212,17 +212,19 @@ struct HeadParams {
 hipError_t launch_head_nms(const HeadParams& p, hipStream_t st);
 size_t head_nms_scratch_bytes(int B, int A);
 
-// Four SiLUs with the two multiplies and the add as packed fp32 operations (v_pk_mul_f32 / v_pk_add_f32: two values per
-// instruction). Same operations and roundings as  x * rcp(1 + exp2(-x * log2e))  element by element, so the same bits; the
-// conv epilogues are VALU-bound on exactly this sequence (28 -> 22 cycles per element).
 #if defined(__HIPCC__)
-typedef float yp_f32x2 __attribute__((ext_vector_type(2)));
 // LDS byte offset of the 16-byte piece `c` of the 64-byte row `row` under the chunk swizzle c ^ (((row >> 2) & 1) << 1), computed from the
 // UNSWIZZLED offset L = row * 64 + c * 16: the swizzle flips bit 5 of L where bit 2 of row = bit 8 of L is set. Written on L, a fragment read
 // costs one add (row offset of the tap, usually a constant) + two bit operations; written on `row`, the compiler spent ~9 VALU instructions per
 // read (PMC on conv_tile1: VALU issue 48 % of the kernel's cycles, matrix pipe busy 30 %).
 __device__ __forceinline__ unsigned swz64(unsigned L) { return L ^ ((L >> 3) & 32u); }
+#endif
 
+// Four SiLUs with the two multiplies and the add as packed fp32 operations (v_pk_mul_f32 / v_pk_add_f32: two values per
+// instruction). Same operations and roundings as  x * rcp(1 + exp2(-x * log2e))  element by element, so the same bits; the
+// conv epilogues are VALU-bound on exactly this sequence (28 -> 22 cycles per element).
+#if defined(__HIPCC__)
+typedef float yp_f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void silu4_packed(float* v) {
 #pragma unroll
     for (int i = 0; i < 4; i += 2) {
