@@ -25,7 +25,8 @@ def _run(family, variant, dtype, shape, conf, seed=0):
 
 
 @pytest.mark.parametrize("family,variant,shape", [("11", "n", (2, 96, 128)), ("v8", "n", (2, 96, 128)), ("11", "x", (1, 64, 64)),
-                                                  ("v8", "m", (1, 64, 96)), ("11", "l", (1, 64, 64)), ("11", "s", (1, 160, 192))])
+                                                  ("v8", "m", (1, 64, 96)), ("11", "l", (1, 64, 64)), ("11", "s", (1, 160, 192)),
+                                                  ("11", "n", (1, 640, 640)), ("v8", "n", (1, 640, 640))])      # full frame: 80x80 / 40x40 / 20x20 maps, N = 400 attention tokens
 def test_layerwise_fp32(family, variant, shape):
     """fp32 engine vs fp32 oracle: every conv-like op (C3k2 / C3k / C2PSA / Segment branches included) within 1e-4 of the tensor's
     max magnitude (5e-4 for the deep l / x graphs on tiny maps, as for YOLOv10-X)."""
