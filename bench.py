@@ -139,6 +139,10 @@ def main():
     gath = [torch.empty((world * B, 300, 6), dtype=torch.float32, device=dev) for _ in range(2)] if use_dist else None
     pending = [None, None]
     nstep = [0]
+    if use_dist:
+        # every rank runs rank 0's tile configurations, so a frame's bf16 detections do not depend on the rank it was sharded to
+        from yolo_puncture_amd.parallel import sync_tuning
+        sync_tuning(eng, (B, S, S), frames)
     eng.set_graph(not a.no_graph)
     if a.no_lanes and not a.no_graph:
         eng._chk(eng.lib.yp_set_graph(eng._h, 2))

@@ -171,6 +171,9 @@ int yp_op_info(const yp_engine* e, int i, char* name, int name_cap, int* kind, d
                double* bytes);                                 /* algorithmic FLOPs / HBM bytes of op i */
 int yp_op_kernel(const yp_engine* e, int i, char* name, int name_cap);   /* device kernel symbol op i launches */
 int yp_op_output(const yp_engine* e, int i, int* tensor, int* coff, int* C); /* output channel slice of op i (tensor<0: user buffers) */
+/* Input view of op i, and `c_read`: the channels a dense conv packed with padded taps actually reads per pixel (> C for 48- / 80-channel
+   inputs: the surplus lanes meet zero weights; their bytes come from the next pixel or, at the very end, from the tensor's zeroed tail). */
+int yp_op_input(const yp_engine* e, int i, int* tensor, int* coff, int* C, int* c_read);
 /* Debug stepping for per-op parity tests ("teacher forcing"): run ONE op of the current plan, and overwrite a
  * channel slice of an engine tensor from fp32 host data [B,H,W,C] (converted to the tensor's storage type). */
 int yp_run_op(yp_engine* e, int i, const uint8_t* in_dev, float* det_out, int32_t* idx_out, float* coeff_out, void* stream);
@@ -190,6 +193,17 @@ int yp_set_nms(yp_engine* e, float conf, float iou);
 
 /* Enable/disable the plan-time autotuner that picks the conv tile configuration per layer (default on). */
 int yp_set_autotune(yp_engine* e, int enable);
+
+/* Tile configurations of the current plan, one id per op (-1 = heuristic / not a tunable conv), as the plan-time autotuner (or an import) left
+   them. bf16 results depend on them in the last bit (fp32 summation order), so a job that wants every rank - or every box - to return identical
+   detections for a frame tunes once and hands the ids round: rank 0 exports after its first forward, the others import BEFORE theirs
+   (yolo_puncture_amd.parallel.sync_tuning does this over torch.distributed; bench.py calls it at N > 1). The reference has no counterpart
+   (one process, PyTorch picks its kernels: yolo_seg/app.py:45-50).
+   yp_tuning_export: returns the number of ops; fills cfg_out[0..n) when it is non-null (cap >= n). Needs a forward on the current plan.
+   yp_tuning_import: plans (B,H,W) and installs the ids for it; every id is validated against this build's configuration tables for its layer
+   (all or nothing, YP_ERR_ARG otherwise). The next yp_forward of that shape neither tunes nor reads the tune cache. */
+int yp_tuning_export(const yp_engine* e, int32_t* cfg_out, int cap);
+int yp_tuning_import(yp_engine* e, int B, int H, int W, const int32_t* cfg, int n);
 
 /* Test hook: force conv tile configuration `cfg` wherever it is valid (-1 = off). Returns the number of configurations. */
 int yp_debug_force_conv_cfg(int cfg);

@@ -5,19 +5,19 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import make_case_family, nchw_to_nhwc, rand_image, rel_err
+from helpers import assert_within_noise_floor, make_case_family, nchw_to_nhwc, rand_image, rel_err
 from oracle import postprocess_oracle as po
 from oracle.yolo_seg_oracle import SegOracle
 
 pytestmark = pytest.mark.gpu
 
 
-def _run(family, variant, dtype, shape, conf, seed=0):
+def _run(family, variant, dtype, shape, conf, seed=0, nc=80):
     from yolo_puncture_amd.engine import Engine
-    st, im = make_case_family(family, variant, 80, seed, shape)
+    st, im = make_case_family(family, variant, nc, seed, shape)
     taps = {}
-    ref = SegOracle(st, family, variant, 80, "fp32", tap=lambda n, x: taps.__setitem__(n, x.float())).forward(im, conf=conf)
-    eng = Engine(variant, 80, True, dtype, 0, state=st, family=family)
+    ref = SegOracle(st, family, variant, nc, "fp32", tap=lambda n, x: taps.__setitem__(n, x.float())).forward(im, conf=conf)
+    eng = Engine(variant, nc, True, dtype, 0, state=st, family=family)
     eng.set_nms(conf, 0.7)
     out = eng.forward(im.cuda())
     torch.cuda.synchronize()
@@ -55,12 +55,16 @@ def test_layerwise_fp32(family, variant, shape):
     assert not bad, bad[:10]
 
 
-@pytest.mark.parametrize("family,variant,conf", [("11", "n", 0.25), ("v8", "n", 0.25), ("11", "n", 0.02), ("v8", "n", 0.02)])
-def test_nms_rows_match_oracle(family, variant, conf):
-    """conf filter + class-aware NMS (`ops.non_max_suppression` [U]) in HIP: the kept rows, best first. fp32 engine, so boxes 5e-3 px /
-    scores 1e-4; anchor index and class identical on every row whose score is not a float near-tie with a neighbour; at conf 0.02
-    hundreds of candidates compete (the oracle's keep count is well below its candidate count)."""
-    st, im, taps, ref, eng, out = _run(family, variant, "fp32", (2, 96, 128), conf)
+@pytest.mark.parametrize("family,variant,conf,nc", [("11", "n", 0.25, 80), ("v8", "n", 0.25, 80), ("11", "n", 0.02, 80), ("v8", "n", 0.02, 80),
+                                                    ("11", "n", 0.25, 1), ("v8", "n", 0.25, 3), ("11", "n", 0.02, 3), ("v8", "n", 0.02, 1)])
+def test_nms_rows_match_oracle(family, variant, conf, nc):
+    """conf filter + class-aware NMS (`ops.non_max_suppression` [U]) in HIP: the kept rows, best first. fp32 engine: anchor index and
+    class identical on every row whose score is not a float near-tie with a neighbour; box / score / coefficient floats within 2 x the
+    reference's own fp32 noise floor (|oracle_fp32 - oracle_fp64| on the same rows); at conf 0.02 hundreds of candidates compete (the
+    oracle's keep count is well below its candidate count). nc = 1 / 3: the class counts of the reference's needle checkpoints
+    (yolo_seg/app.py:218-223) - a 1- / 3-wide fp32 class map through head_nms_decode_kernel."""
+    st, im, taps, ref, eng, out = _run(family, variant, "fp32", (2, 96, 128), conf, nc=nc)
+    ref64 = SegOracle(st, family, variant, nc, "fp64").forward(im, conf=conf)
     det, idx, cf = out["det"].cpu(), out["idx"].cpu().long(), out["coeff"].cpu()
     for b in range(2):
         want, widx, wcf = ref["det"][b], ref["idx"][b], ref["coeff"][b]
@@ -77,9 +81,13 @@ def test_nms_rows_match_oracle(family, variant, conf):
         clear[:-1] &= gap > 1e-5
         assert clear.float().mean() > 0.5
         assert torch.equal(idx[b, :n][clear], widx[clear]) and torch.equal(det[b, :n, 5][clear], want[:, 5][clear])
-        assert float((det[b, :n, 4] - want[:, 4]).abs().max()) < 1e-4
-        assert float((det[b, :n, :4] - want[:, :4])[clear].abs().max()) < 5e-3
-        assert float((cf[b, :n] - wcf)[clear].abs().max()) < 1e-3
+        w64, i64, c64 = ref64["det"][b], ref64["idx"][b], ref64["coeff"][b]
+        assert w64.shape[0] == n, "fp32 and fp64 oracle keep different row counts: pick another seed / conf for this case"
+        same = clear & (i64 == widx) & (w64[:, 5].float() == want[:, 5]) & (idx[b, :n] == widx)
+        assert same.float().mean() > 0.5
+        assert_within_noise_floor(f"[{b}] NMS rows: boxes [px]", det[b, :n, :4][same], want[:, :4][same], w64[:, :4][same], 1e-3)
+        assert_within_noise_floor(f"[{b}] NMS rows: scores", det[b, :n, 4][same], want[:, 4][same], w64[:, 4][same], 1e-3)
+        assert_within_noise_floor(f"[{b}] NMS rows: mask coefficients", cf[b, :n][same], wcf[same], c64[same], 1e-3)
     pr = nchw_to_nhwc(ref["proto"])
     assert rel_err(eng.proto(), pr) < 1e-4
     # the thresholds live in device memory: a higher conf on the same engine returns the prefix of rows above it (NMS is monotone)
@@ -95,7 +103,9 @@ def test_nms_rows_match_oracle(family, variant, conf):
 @pytest.mark.parametrize("family,variant", [("11", "n"), ("v8", "n"), ("11", "s")])
 def test_bf16_accuracy_and_graph(family, variant):
     """bf16 engine, hipGraph replay with the head lanes: error of the head's raw logits against the fp32 oracle at most 1.25 x the
-    bf16-emulating oracle's on average over the head tensors (the YOLOv10 bound; 1.5 x per tensor), and replay == eager bit for bit."""
+    bf16-emulating oracle's for every head tensor (the YOLOv10 bound), and replay == eager bit for bit. The tile configurations are the
+    heuristic's (autotune off): a function of the build and the shape only, so the measured ratios are the same numbers on every box
+    (with the tuner on they depended on which configurations won the timing on that box)."""
     from yolo_puncture_amd.engine import Engine
     shape = (2, 128, 160)
     st, im = make_case_family(family, variant, 80, 0, shape)
@@ -103,22 +113,19 @@ def test_bf16_accuracy_and_graph(family, variant):
     SegOracle(st, family, variant, 80, "fp32", tap=lambda n, x: t32.__setitem__(n, x.float())).forward(im)
     SegOracle(st, family, variant, 80, "bf16emu", tap=lambda n, x: t16.__setitem__(n, x.float())).forward(im)
     eng = Engine(variant, 80, True, "bf16", 0, state=st, family=family)
+    eng.set_autotune(False)
     imc = im.cuda()
     ref = {k: v.clone() for k, v in eng.forward(imc).items() if v is not None}
     torch.cuda.synchronize()
     hi = 22 if family == "v8" else 23
-    # Two bf16 trajectories that differ in one rounding decorrelate down the network, and the engine's depends on which tile
-    # configurations its tuner picked on this box (fp32 summation order): per tensor the ratio scatters (1.27 was seen once on one
-    # P4 class map of 11-s), so each tensor gets 1.5 x and the ratio of the sums over all head tensors the 1.25 x of the YOLOv10 bound.
-    tot_eng = tot_emu = 0.0
+    worst = 0.0
     for n in [f"model.{hi}.cv2.{l}.2" for l in range(3)] + [f"model.{hi}.cv3.{l}.2" for l in range(3)] + [f"model.{hi}.cv4.{l}.2" for l in range(3)] + [f"model.{hi}.proto.cv3"]:
         got = eng.read_tensor(eng.find_tensor(n))
         truth = nchw_to_nhwc(t32[n])
         e_eng, e_emu = float((got - truth).abs().mean()), float((nchw_to_nhwc(t16[n]) - truth).abs().mean())
-        assert e_eng <= 1.5 * e_emu + 1e-6, (n, e_eng, e_emu)
-        tot_eng += e_eng / max(e_emu, 1e-12)
-        tot_emu += 1.0
-    assert tot_eng <= 1.25 * tot_emu, (tot_eng / tot_emu)
+        worst = max(worst, e_eng / max(e_emu, 1e-12))
+        print(f"{family}{variant} {n}: engine {e_eng:.4e}  bf16-emulating oracle {e_emu:.4e}  ratio {e_eng / max(e_emu, 1e-12):.3f}")
+        assert e_eng <= 1.25 * e_emu + 1e-6, (n, e_eng, e_emu)
     eng.set_graph(True)
     for _ in range(3):
         out = eng.forward(imc)
@@ -128,22 +135,23 @@ def test_bf16_accuracy_and_graph(family, variant):
     eng.close()
 
 
-@pytest.mark.parametrize("family", ["11", "v8"])
-def test_facade_predict_and_pt_roundtrip(family, tmp_path):
+@pytest.mark.parametrize("family,nc", [("11", 80), ("v8", 80), ("11", 1), ("v8", 3)])
+def test_facade_predict_and_pt_roundtrip(family, nc, tmp_path):
     """`YOLO("<ckpt>.pt").predict(frame, conf, retina_masks)` on a yolo11n-seg / yolov8n-seg layout checkpoint (what app.py:45-50 does):
     family / variant / nc detected from the state dict, boxes + masks against the oracle pipeline."""
     from yolo_puncture_amd import YOLO
     from yolo_puncture_amd.weights import read_ultralytics_pt, save_as_ultralytics_pt
-    st, ims = make_case_family(family, "n", 80, 0, (1, 384, 640))     # calibrated on this very frame (384x640 letterboxes to itself)
+    st, ims = make_case_family(family, "n", nc, 0, (1, 384, 640))     # calibrated on this very frame (384x640 letterboxes to itself)
     frame = ims[0].numpy()
     boxed, _ = po.letterbox(frame)
     assert boxed.shape == frame.shape and np.array_equal(boxed, frame)
     path = str(tmp_path / f"{family}n-seg.pt")
     save_as_ultralytics_pt(st, path)
     st_rt, meta = read_ultralytics_pt(path)
-    assert meta["family"] == family and meta["variant"] == "n" and meta["nc"] == 80 and meta["seg"]
+    assert meta["family"] == family and meta["variant"] == "n" and meta["nc"] == nc and meta["seg"]
     conf = 0.3
-    o = SegOracle(st_rt, family, "n", 80, "fp32").forward(torch.from_numpy(boxed[None]), conf=conf)
+    o = SegOracle(st_rt, family, "n", nc, "fp32").forward(torch.from_numpy(boxed[None]), conf=conf)
+    o64 = SegOracle(st_rt, family, "n", nc, "fp64").forward(torch.from_numpy(boxed[None]), conf=conf)
     det = o["det"][0].clone()
     H, W = boxed.shape[:2]
     oh, ow = frame.shape[:2]
@@ -161,7 +169,12 @@ def test_facade_predict_and_pt_roundtrip(family, tmp_path):
     clear[1:] &= gap > 1e-5
     clear[:-1] &= gap > 1e-5
     assert np.array_equal(b.cls[clear], det[:, 5].numpy()[clear])
-    assert np.abs(b.xyxy - det[:, :4].numpy())[clear].max() < 5e-3 and np.abs(b.conf - s).max() < 1e-4
+    det64 = o64["det"][0].clone()
+    det64[:, :4] = po.scale_boxes((H, W), det64[:, :4], (oh, ow))
+    assert det64.shape[0] == n
+    same = torch.from_numpy(clear) & (det64[:, 5].float() == det[:, 5]) & (o64["idx"][0] == o["idx"][0])
+    assert_within_noise_floor("facade boxes [px]", torch.from_numpy(b.xyxy)[same], det[:, :4][same], det64[:, :4][same], 1e-3)
+    assert_within_noise_floor("facade conf", torch.from_numpy(b.conf)[same], det[:, 4][same], det64[:, 4][same], 1e-3)
     diff = (r.masks.data.cpu()[torch.from_numpy(clear)] != want_masks[torch.from_numpy(clear)]).float().mean().item()
     assert diff < 2e-4, diff
     assert len(r.masks.xy) == n

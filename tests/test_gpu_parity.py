@@ -18,14 +18,14 @@ def _engine(variant, nc, seg, dtype, st):
     return Engine(variant, nc, seg, dtype, 0, state=st)
 
 
-def _layerwise(variant, seg, dtype, mode, shape, seed=0):
+def _layerwise(variant, seg, dtype, mode, shape, seed=0, nc=80):
     """Run engine + oracle, compare every conv-like op's output slice with the oracle tap of the same name.
     -> list of (op name, kind, rel err) in execution order, final outputs of both."""
     from oracle.yolov10_oracle import Oracle
-    st, im = make_case(variant, 80, seg, seed, shape)
+    st, im = make_case(variant, nc, seg, seed, shape)
     taps = {}
-    ref = Oracle(st, variant, 80, seg, mode, tap=lambda n, x: taps.__setitem__(n, x.float())).forward(im)
-    eng = _engine(variant, 80, seg, dtype, st)
+    ref = Oracle(st, variant, nc, seg, mode, tap=lambda n, x: taps.__setitem__(n, x.float())).forward(im)
+    eng = _engine(variant, nc, seg, dtype, st)
     out = eng.forward(im.cuda())
     torch.cuda.synchronize()
     ops = eng.plan(*shape)
@@ -92,20 +92,33 @@ def _ulps_bf16(got, want):
                          [("s", False, (1, 256, 256), c, True) for c in range(500, 505)] +    # stride-2 halo family: model.1 / .3 / .17 all valid here
                          [("x", False, (1, 64, 64), c, True) for c in (801, 803, 807)])       # pixels-direct 1x1 with Cin % 64 == 32 (80 / 160 / 480-channel layers of v10-X)
 def test_per_op_bf16_teacher_forced(variant, seg, shape, cfg, fuse, monkeypatch):
+    _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, 80)
+
+
+@pytest.mark.parametrize("variant,seg,shape,nc", [("s", True, (3, 96, 160), 1), ("s", True, (3, 96, 160), 3), ("n", False, (2, 256, 384), 1),
+                                                  ("s", False, (1, 160, 192), 3)])
+def test_per_op_bf16_small_nc(variant, seg, shape, nc, monkeypatch):
+    """The class counts of the reference's checkpoints - needle fine-tunes, nc = 1 or a handful (yolo_seg/app.py:218-223,
+    yolo_with_deva.py:226): a 1- / 3-channel fp32 class map through the conv epilogues' 4-channel lane stores, the class-max pass'
+    scalar branch and the class branch's narrow (max(ch0, min(nc,100)) wide) depthwise -> pointwise pairs. Same per-op contract as nc = 80."""
+    _per_op_bf16(variant, seg, shape, -1, True, monkeypatch, nc)
+
+
+def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc):
     """bf16 kernels one at a time: every op consumes the ORACLE's (bf16emu) tensors - after each op its output
     slice is overwritten with the oracle's tap - so the only admissible difference is the bf16 rounding of an
     fp32 sum taken in a different order: <= 1 bf16 ulp per element, on a small fraction of the elements.
     (The chained bf16 forward cannot be compared this tightly: once two bf16 trajectories differ they decorrelate
     to the bf16 noise floor, see test_end_to_end_bf16_accuracy.)"""
     from oracle.yolov10_oracle import Oracle
-    st, im = make_case(variant, 80, seg, 0, shape)
+    st, im = make_case(variant, nc, seg, 0, shape)
     taps = {}
-    Oracle(st, variant, 80, seg, "bf16emu", tap=lambda n, x: taps.__setitem__(n, x.float())).forward(im)
+    Oracle(st, variant, nc, seg, "bf16emu", tap=lambda n, x: taps.__setitem__(n, x.float())).forward(im)
     from yolo_puncture_amd.engine import load_library
     assert load_library().yp_debug_force_conv_cfg(cfg) >= 14    # cfg >= 0: every conv that admits this tile config uses it
     if not fuse:
         monkeypatch.setenv("YOLOP_NO_FUSE", "1")     # read at yp_create: the dw / pw kernels of the fused pairs run unfused
-    eng = _engine(variant, 80, seg, "bf16", st)
+    eng = _engine(variant, nc, seg, "bf16", st)
     if cfg >= 0:
         eng.set_autotune(False)
     imc = im.cuda()
@@ -166,7 +179,7 @@ def test_per_op_bf16_teacher_forced(variant, seg, shape, cfg, fuse, monkeypatch)
     eng.close()
     load_library().yp_debug_force_conv_cfg(-1)
     assert len(rows) > 50
-    assert nfused == 0 if not fuse else (nfused > 0 or shape != (2, 256, 384))
+    assert nfused == 0 if not fuse else (nfused > 0 or shape != (2, 256, 384) or nc != 80)
 
 
 def _final_report(res, ref, k):
@@ -177,13 +190,18 @@ def _final_report(res, ref, k):
                 score=float((det[..., 4] - rdet[..., 4]).abs().max()), agree=float(same.float().mean()))
 
 
-@pytest.mark.parametrize("variant,seg,shape", [("n", True, (2, 96, 128)), ("s", False, (2, 320, 320)),
-                                               ("n", False, (1, 640, 640))])
-def test_end_to_end_fp32(variant, seg, shape):
-    """[B,300,6] + anchor indices, fp32 engine vs fp32 oracle. Box tolerance 5e-3 px, score 1e-4: the oracle
-    itself moves by 1e-3 px / 7e-6 between fp32 and fp64 on these nets (measured); indices and
-    class ids must be identical on every row whose score gap to its neighbours exceeds 1e-5."""
-    rows, res, ref = _layerwise(variant, seg, "fp32", "fp32", shape)
+@pytest.mark.parametrize("variant,seg,shape,nc", [("n", True, (2, 96, 128), 80), ("s", False, (2, 320, 320), 80),
+                                                  ("n", False, (1, 640, 640), 80), ("n", True, (2, 96, 128), 1), ("s", False, (2, 320, 320), 3)])
+def test_end_to_end_fp32(variant, seg, shape, nc):
+    """[B,300,6] + anchor indices, fp32 engine vs the oracle. Indices and class ids identical on every row whose score gap to its
+    neighbours exceeds 1e-5; box / score / coefficient / prototype floats within 2 x the reference's own fp32 noise floor, measured per
+    case as |oracle_fp32 - oracle_fp64| (helpers.assert_within_noise_floor; north_star's 1e-3 is printed beside both numbers).
+    nc = 1 / 3: the class counts of the reference's needle checkpoints (yolo_seg/app.py:218-223)."""
+    from oracle.yolov10_oracle import Oracle
+    from helpers import assert_within_noise_floor
+    rows, res, ref = _layerwise(variant, seg, "fp32", "fp32", shape, nc=nc)
+    st, im = make_case(variant, nc, seg, 0, shape)
+    ref64 = Oracle(st, variant, nc, seg, "fp64").forward(im)
     k = ref["det"].shape[1]
     rep = _final_report(res, ref, k)
     s = ref["det"][..., 4]
@@ -192,14 +210,18 @@ def test_end_to_end_fp32(variant, seg, shape):
     safe[:, 1:] &= gap > 1e-5
     safe[:, :-1] &= gap > 1e-5
     idx_ok = (res["idx"][:, :k].long() == ref["idx"]) & (res["det"][:, :k, 5] == ref["det"][..., 5])
-    print(variant, shape, rep, "near-tie rows:", float((~safe).float().mean()))
+    print(variant, shape, "nc", nc, rep, "near-tie rows:", float((~safe).float().mean()))
     assert bool(idx_ok[safe].all()), "index/class mismatch on a row with a clear score gap"
-    assert rep["box"] < 5e-3 and rep["score"] < 1e-4, rep
+    assert safe.float().mean() > 0.5
+    # rows on which engine, fp32 oracle and fp64 oracle all hold the same (anchor, class): the floats of those rows are comparable
+    same = idx_ok & (ref64["idx"] == ref["idx"]) & (ref64["det"][..., 5].float() == ref["det"][..., 5])
+    assert same.float().mean() > 0.9, float(same.float().mean())
+    det = res["det"][:, :k]
+    assert_within_noise_floor("boxes [px]", det[..., :4][same], ref["det"][..., :4][same], ref64["det"][..., :4][same], 1e-3)
+    assert_within_noise_floor("scores", det[..., 4][same], ref["det"][..., 4][same], ref64["det"][..., 4][same], 1e-3)
     if seg:
-        cf = res["coeff"][:, :k]
-        assert float((cf - ref["coeff"])[idx_ok].abs().max()) < 1e-3
-        pr = nchw_to_nhwc(ref["proto"])
-        assert rel_err(res["proto"], pr) < 1e-4
+        assert_within_noise_floor("mask coefficients", res["coeff"][:, :k][same], ref["coeff"][same], ref64["coeff"][same], 1e-3)
+        assert_within_noise_floor("prototypes", res["proto"], nchw_to_nhwc(ref["proto"]), nchw_to_nhwc(ref64["proto"]), 1e-3)
 
 
 @pytest.mark.parametrize("variant,seg,shape", [("n", True, (2, 96, 128)), ("s", False, (2, 320, 320))])
@@ -269,3 +291,91 @@ def test_graph_replay_matches_eager():
         for k in ref:
             assert torch.equal(out[k], ref[k]), k
     eng.close()
+
+
+def _poison_everything(eng):
+    """Fill every engine tensor with bit patterns that read as bf16 NaN: bf16 tensors get NaN, fp32 tensors a finite float
+    (bits 0x3F80FFFF) whose LOW half - the first two bytes in memory, what a bf16 over-read of it sees - is 0xFFFF."""
+    bad32 = torch.tensor([0x3F80FFFF], dtype=torch.int32).view(torch.float32).item()
+    for t in eng.tensors():
+        fill = bad32 if t["f32"] else float("nan")
+        eng.write_tensor(t["index"], 0, torch.full(t["shape"], fill, dtype=torch.float32))
+
+
+@pytest.mark.parametrize("family,variant,seg", [("v10", "x", False), ("v8", "m", True), ("v10", "x", True)])
+def test_padded_tap_overread_reads_zeroed_tail(family, variant, seg):
+    """Dense convs on 48- / 80-channel inputs run with padded taps (WeightDesc::cin_pad): at the last pixel of the last image they read up
+    to 32 bytes past their input tensor, times zero weights - NaN bit patterns there would poison the bottom-right anchor (NaN * 0 = NaN
+    on the matrix cores). Every such tensor owns a tail that allocate_plan zeroes on EVERY layout. The test plans a large shape, fills the
+    whole arena's tensors with bf16-NaN patterns, re-plans a smaller shape into the kept arena (so tensors land on stale bytes, fp32 logits
+    right behind bf16 activations) and requires every padded-tap conv's output - last pixel of the last image included - to be finite."""
+    from yolo_puncture_amd.engine import Engine
+    if family == "v10":
+        st, im = make_case(variant, 80, seg, 0, (1, 64, 64))
+        eng = Engine(variant, 80, seg, "bf16", 0, state=st)
+    else:
+        from helpers import make_case_family
+        st, im = make_case_family(family, variant, 80, 0, (1, 64, 64))
+        eng = Engine(variant, 80, True, "bf16", 0, state=st, family=family)
+    eng.set_autotune(False)
+    big = torch.zeros((2, 96, 128, 3), dtype=torch.uint8).cuda()
+    eng.forward(big)
+    torch.cuda.synchronize()
+    _poison_everything(eng)
+    imc = im.cuda()
+    out = eng.forward(imc)                      # re-plan into the kept (poisoned) arena
+    torch.cuda.synchronize()
+    ops = eng.plan(1, 64, 64)
+    padded = [(i, o) for i, o in enumerate(ops) if o["kind"] == "conv" and o["c_read"] > o["in"][2] and o["kernel"] != "-"]
+    assert padded, "this model should have padded-tap convs"
+    assert bool(torch.isfinite(out["det"]).all())
+    for i, o in padded:
+        t, c0, cc = o["out"]
+        y = eng.read_tensor(t)[..., c0:c0 + cc]
+        assert bool(torch.isfinite(y).all()), (o["name"], o["in"], o["c_read"])
+        assert bool(torch.isfinite(y[-1, -1, -1]).all())
+    # and directly: poison again (tails included? no - write_tensor only touches payloads), run each padded op alone, check again
+    _poison_everything(eng)
+    for i, o in padded:
+        ti, ci, cin = o["in"]
+        shp = eng.tensors()[ti]["shape"]
+        eng.write_tensor(ti, 0, torch.zeros(shp))            # a finite input; everything else (the NEXT tensor included) stays poisoned
+        eng.run_op(i, imc, out)
+        t, c0, cc = o["out"]
+        y = eng.read_tensor(t)[..., c0:c0 + cc]
+        assert bool(torch.isfinite(y).all()), (o["name"], "next tensor poisoned")
+    eng.close()
+
+
+def test_tuning_export_import_reproduces_bits():
+    """bf16 results depend on the conv tile configurations in the last bit (fp32 summation order). An engine that IMPORTS another engine's
+    configurations (what parallel.sync_tuning does between ranks, include/yolop.h yp_tuning_*) must reproduce its outputs bit for bit, whatever
+    its own tuner would have picked; an id that is not launchable for its layer is refused."""
+    from yolo_puncture_amd.engine import YolopError
+    shape = (3, 160, 192)
+    st, im = make_case("s", 80, True, 0, shape)
+    imc = im.cuda()
+    a = _engine("s", 80, True, "bf16", st)
+    ref = {k: v.clone() for k, v in a.forward(imc).items() if v is not None}
+    torch.cuda.synchronize()
+    cfgs = a.tuning_export()
+    ops = a.plan(*shape)
+    assert len(cfgs) == len(ops) and any(c >= 100 for c in cfgs)
+    logits_a = a.read_tensor(a.find_tensor("model.23.one2one_cv3.0.2"))
+    a.close()
+    b = _engine("s", 80, True, "bf16", st)
+    b.set_autotune(False)                                    # b's own choice would be the heuristic: different kernels for many layers
+    b.tuning_import(*shape, cfgs)
+    out = b.forward(imc)
+    torch.cuda.synchronize()
+    assert b.tuning_export() == cfgs
+    assert [o["kernel"] for o in b.plan(*shape)] == [o["kernel"] for o in ops]
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.equal(b.read_tensor(b.find_tensor("model.23.one2one_cv3.0.2")), logits_a)
+    bad = list(cfgs)
+    j = next(i for i, o in enumerate(ops) if o["kind"] == "conv" and o["kernel"] != "-" and cfgs[i] >= 100)
+    bad[j] = 999                                             # conv_ks id beyond its table
+    with pytest.raises(YolopError):
+        b.tuning_import(*shape, bad)
+    b.close()

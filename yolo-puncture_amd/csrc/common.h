@@ -243,6 +243,7 @@ __device__ __forceinline__ void silu4_packed(float* v) {
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st);
 hipError_t launch_conv_igemm(const ConvParams& p, int dtype, hipStream_t st);   // always the register-staged kernel (dilation, ReLU, any Cin % 8 == 0)
 const char* conv_kernel_name(const ConvParams& p, int dtype);
+bool conv_cfg_usable(const ConvParams& p, int dtype, int cfg);   // a configuration id from a cache file / yp_tuning_import is launchable for p
 hipError_t launch_conv_dma(const ConvParams& p, hipStream_t st);
 bool conv_dma_supported(const ConvParams& p);
 const char* conv_dma_kernel_name(const ConvParams& p);

@@ -274,6 +274,24 @@ static int halo_choice(const ConvParams& p, int dtype) {
     return -1;
 }
 
+// Is tile configuration id `cfg` (the autotuner's numbering: < 100 conv_dma, 100+ conv_halo, 200+ conv_halo_p, 300+ conv_dma_p, 400+ conv_dma_lc,
+// 500+ conv_halo_s2, 600+ conv_tile1, 700+ conv_wreg, 800+ conv_pxd, 900+ conv_ks; -1 = heuristic) one this build can launch for p? Used for
+// configurations that come from outside the tuner (tune cache files, yp_tuning_import).
+bool conv_cfg_usable(const ConvParams& p, int dtype, int cfg) {
+    if (cfg == -1) return true;
+    if (dtype != DT_BF16 || cfg < -1) return false;
+    if (cfg >= 900) return cfg - 900 < conv_ks_num_cfgs() && p.x2_C == 0 && conv_ks_cfg_valid(p, cfg - 900);
+    if (cfg >= 800) return cfg - 800 < conv_pxd_num_cfgs() && conv_pxd_cfg_valid(p, cfg - 800);
+    if (cfg >= 700) return cfg - 700 < conv_wreg_num_cfgs() && p.x2_C == 0 && conv_wreg_cfg_valid(p, cfg - 700);
+    if (cfg >= 600) return cfg - 600 < conv_tile1_num_cfgs() && p.x2_C == 0 && conv_tile1_cfg_valid(p, cfg - 600);
+    if (cfg >= 500) return cfg - 500 < conv_halo_s2_num_cfgs() && p.x2_C == 0 && conv_halo_s2_cfg_valid(p, cfg - 500);
+    if (cfg >= 400) return cfg - 400 < conv_dma_lc_num_cfgs() && conv_dma_lc_cfg_valid(p, cfg - 400);
+    if (cfg >= 300) return cfg - 300 < conv_dma_p_num_cfgs() && conv_dma_p_cfg_valid(p, cfg - 300);
+    if (cfg >= 200) return cfg - 200 < conv_halo_p_num_cfgs() && p.x2_C == 0 && conv_halo_p_cfg_valid(p, cfg - 200);
+    if (cfg >= 100) return cfg - 100 < conv_halo_num_cfgs() && p.x2_C == 0 && conv_halo_cfg_valid(p, cfg - 100);
+    return cfg < conv_dma_num_cfgs() && p.x2_C == 0 && conv_dma_supported(p) && conv_dma_cfg_valid(p, cfg);
+}
+
 const char* conv_kernel_name(const ConvParams& p, int dtype) {
     const int h = halo_choice(p, dtype);
     if (h >= 900) return conv_ks_kernel_name(h - 900);

@@ -785,21 +785,31 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
 
 static int allocate_plan(yp_engine& e) {
     if (e.allocated) return YP_OK;
+    // A dense conv packed with padded taps (WeightDesc::cin_pad > Cin, see conv_params) reads cin_pad channels per pixel: at the last
+    // pixel of the last image that is up to (cin_pad - Cin) * 2 < 64 bytes past the end of its input tensor, multiplied by zero weights.
+    // Those bytes must be finite bf16 patterns (NaN * 0 = NaN on the matrix cores), so every such tensor owns a 64-byte tail behind its
+    // payload that is part of its slot and is zeroed on EVERY layout (a re-plan into the kept arena leaves stale fp32 / u32 bytes there).
+    std::vector<char> tail(e.tensors.size(), 0);
+    for (const auto& o : e.ops)
+        if (o.kind == OP_CONV && o.widx >= 0 && o.in.t >= 0 && e.weights[o.widx].cin_pad > o.in.C) tail[o.in.t] = 1;
+    auto slot = [&](size_t i) { return (e.tensors[i].bytes + (tail[i] ? 64 : 0) + 255) & ~(size_t)255; };
     size_t total = 0;
-    for (auto& t : e.tensors) total += (t.bytes + 255) & ~(size_t)255;
+    for (size_t i = 0; i < e.tensors.size(); ++i) total += slot(i);
     HIPCHK(hipSetDevice(e.device));
     total += 4096;                                   // (slack behind the last tensor: padded-tap reads of conv_igemm's plain loads)
     if (total > e.arena_bytes) {
         if (e.arena) HIPCHK(hipFree(e.arena));
         e.arena = nullptr;
         HIPCHK(hipMalloc(&e.arena, total));
-        HIPCHK(hipMemset(e.arena, 0, total));        // every byte a kernel may over-read is a finite number from here on
+        HIPCHK(hipMemset(e.arena, 0, total));
         e.arena_bytes = total;
     }
     size_t off = 0;
-    for (auto& t : e.tensors) {
+    for (size_t i = 0; i < e.tensors.size(); ++i) {
+        TensorDesc& t = e.tensors[i];
         t.ptr = (char*)e.arena + off;
-        off += (t.bytes + 255) & ~(size_t)255;
+        if (tail[i]) HIPCHK(hipMemset((char*)t.ptr + t.bytes, 0, slot(i) - t.bytes));
+        off += slot(i);
     }
     {
         size_t A = 0;
@@ -1168,12 +1178,43 @@ static int autotune(yp_engine& e) {
 
 // Optional on-disk cache of the autotuner's choices (env YOLOP_TUNE_CACHE=<path prefix>): one file per
 // (variant, task, dtype, B, H, W), lines "<op name> <cfg>". Lets a profiled run skip the tuning launches.
+static const int TUNE_TABLE_VERSION = 3;
 static std::string tune_cache_path(const yp_engine& e) {
     const char* pre = std::getenv("YOLOP_TUNE_CACHE");
     if (!pre || !*pre) return "";
     std::ostringstream os;
-    os << pre << "_" << (char)e.desc.variant << (e.desc.task ? "seg" : "det") << "_nc" << e.desc.nc << "_dt" << e.dtype << "_" << e.pB << "x" << e.pH << "x" << e.pW << ".txt";
+    // "t<N>": bump TUNE_TABLE_VERSION whenever configuration ids are added, removed or renumbered - older files are then simply not found
+    os << pre << "_f" << e.desc.family << (char)e.desc.variant << (e.desc.task ? "seg" : "det") << "_nc" << e.desc.nc << "_dt" << e.dtype << "_" << e.pB << "x" << e.pH << "x" << e.pW
+       << "_t" << TUNE_TABLE_VERSION << ".txt";
     return os.str();
+}
+// Install tile configurations that did not come from this process's tuner (cache file, yp_tuning_import): one id per op of the current
+// plan (ignored for ops that are not tunable convs). Every id is checked with the predicates the tuner itself uses; all or nothing.
+static ConvParams tune_params(const yp_engine& e, const Op& o) {
+    if (o.kind == OP_CONV) return conv_params(e, o);
+    ConvParams p{};
+    p.Cin = o.in.C; p.Cout = o.out.C; p.ks = 1; p.Kpad = e.weights[o.widx].Kpad; p.M = e.pB * e.tensors[o.in.t].H * e.tensors[o.in.t].W;
+    p.x_bytes = e.tensors[o.in.t].bytes; p.w_bytes = e.weights[o.widx].mat_bytes;
+    return p;
+}
+static bool apply_tuning(yp_engine& e, const int* cfgs, int n) {
+    if (n != (int)e.ops.size()) return false;
+    for (size_t i = 0; i < e.ops.size(); ++i) {
+        const Op& o = e.ops[i];
+        if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.skip) continue;
+        ConvParams p = tune_params(e, o);
+        p.cfg = -1;
+        if (!conv_cfg_usable(p, e.dtype, cfgs[i])) return false;
+    }
+    for (size_t i = 0; i < e.ops.size(); ++i) {
+        Op& o = e.ops[i];
+        if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.skip) continue;   // a fused op keeps its own symbol / id
+        o.cfg = cfgs[i];
+        ConvParams p = tune_params(e, o);
+        p.cfg = o.cfg;
+        o.kernel = conv_kernel_name(p, e.dtype);
+    }
+    return true;
 }
 static bool load_tune_cache(yp_engine& e) {
     const std::string path = tune_cache_path(e);
@@ -1184,18 +1225,15 @@ static bool load_tune_cache(yp_engine& e) {
     std::string name;
     int cfg;
     while (f >> name >> cfg) m[name] = cfg;
-    for (Op& o : e.ops)
-        if (o.kind == OP_CONV || o.kind == OP_CONVT) {
-            auto it = m.find(o.name);
-            if (it == m.end()) return false;
-        }
-    for (Op& o : e.ops)
-        if (o.kind == OP_CONV || o.kind == OP_CONVT) {
-            o.cfg = m[o.name];
-            if (o.fused2) { o.cfg = 500 + conv_halo_s2_pw_cfg(conv_params(e, o)); continue; }
-            if (o.kind == OP_CONV && !o.fused && !o.fused4 && !o.skip) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);   // a fused op keeps its own symbol
-        }
-    return true;
+    std::vector<int> cfgs(e.ops.size(), -1);
+    for (size_t i = 0; i < e.ops.size(); ++i) {
+        const Op& o = e.ops[i];
+        if (o.kind != OP_CONV && o.kind != OP_CONVT) continue;
+        auto it = m.find(o.name);
+        if (it == m.end()) return false;
+        cfgs[i] = it->second;
+    }
+    return apply_tuning(e, cfgs.data(), (int)cfgs.size());     // an id this build cannot launch for its layer = a cache miss
 }
 static void save_tune_cache(const yp_engine& e) {
     const std::string path = tune_cache_path(e);
@@ -1646,6 +1684,16 @@ int yp_op_output(const yp_engine* e, int i, int* tensor, int* coff, int* C) {
     return YP_OK;
 }
 
+int yp_op_input(const yp_engine* e, int i, int* tensor, int* coff, int* C, int* c_read) {
+    if (!e || i < 0 || i >= (int)e->ops.size()) return fail(YP_ERR_ARG, "bad op index");
+    const Op& o = e->ops[i];
+    if (tensor) *tensor = o.in.t;
+    if (coff) *coff = o.in.coff;
+    if (C) *C = o.in.C;
+    if (c_read) *c_read = (o.kind == OP_CONV && o.widx >= 0 && e->weights[o.widx].cin_pad > o.in.C) ? e->weights[o.widx].cin_pad : o.in.C;
+    return YP_OK;
+}
+
 int yp_run_op(yp_engine* e, int i, const uint8_t* in_dev, float* det_out, int32_t* idx_out, float* coeff_out, void* stream) {
     if (!e || i < 0 || i >= (int)e->ops.size()) return fail(YP_ERR_ARG, "bad op index");
     if (!e->allocated) return fail(YP_ERR_STATE, "no forward has run yet");
@@ -1921,6 +1969,33 @@ int yp_set_autotune(yp_engine* e, int enable) {
     if (!e) return fail(YP_ERR_ARG, "null engine");
     e->tune = enable != 0;
     e->tuned.clear();                    // (configurations remembered per shape were chosen under the other setting)
+    return YP_OK;
+}
+
+int yp_tuning_export(const yp_engine* e, int32_t* cfg_out, int cap) {
+    if (!e) return fail(YP_ERR_ARG, "null engine");
+    if (!e->allocated) return fail(YP_ERR_STATE, "yp_tuning_export: no forward has run on the current plan");
+    const int n = (int)e->ops.size();
+    if (cfg_out) {
+        if (cap < n) return fail(YP_ERR_ARG, "yp_tuning_export: %d ops, buffer holds %d", n, cap);
+        for (int i = 0; i < n; ++i) cfg_out[i] = e->ops[i].cfg;
+    }
+    return n;
+}
+
+int yp_tuning_import(yp_engine* e, int B, int H, int W, const int32_t* cfg, int n) {
+    if (!e || !cfg) return fail(YP_ERR_ARG, "null argument");
+    if (!e->finalized) return fail(YP_ERR_STATE, "yp_finalize has not been called");
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());                 // the plan (and with it every launch parameter) changes under nothing in flight
+    e->planned = false;                             // re-derive the plan's fusion decisions from scratch for (B,H,W)
+    int rc = make_plan(*e, B, H, W);
+    if (rc != YP_OK) return rc;
+    if (n != (int)e->ops.size()) return fail(YP_ERR_ARG, "yp_tuning_import: %d ids for a plan of %zu ops", n, e->ops.size());
+    std::vector<int> v(cfg, cfg + n);
+    if (!apply_tuning(*e, v.data(), n)) return fail(YP_ERR_ARG, "yp_tuning_import: a configuration id is not launchable for its layer in this build");
+    finish_kernel_names(*e);
+    remember_tuning(*e);                            // prepare() recalls it instead of tuning
     return YP_OK;
 }
 

@@ -85,7 +85,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     for fn in ("yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy"):
         getattr(lib, fn).restype = C.c_int
     for fn in ("yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight", "yp_finalize",
-               "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output", "yp_tensor_count",
+               "yp_forward", "yp_proto", "yp_masks", "yp_plan", "yp_op_info", "yp_op_output", "yp_op_input", "yp_tensor_count",
                "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op", "yp_tensor_write",
                "yp_op_kernel", "yp_set_autotune", "yp_debug_force_conv_cfg", "yp_debug_ablation"):
         getattr(lib, fn).restype = C.c_int
@@ -95,9 +95,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
-           "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output",
+           "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output", "yp_op_input",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_contour_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
+           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_tuning_export", "yp_tuning_import", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_contour_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy",
            "yp_u2net_create", "yp_u2net_destroy", "yp_u2net_weight_count", "yp_u2net_weight_info", "yp_u2net_set_weight", "yp_u2net_finalize",
            "yp_u2net_forward", "yp_u2net_set_graph", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
@@ -239,6 +239,20 @@ class Engine:
     def set_autotune(self, enable: bool) -> None:
         self._chk(self.lib.yp_set_autotune(self._h, 1 if enable else 0))
 
+    def tuning_export(self) -> List[int]:
+        """Tile configuration id per op of the current plan (after a forward): what `tuning_import` takes on another engine / rank."""
+        n = self._chk(self.lib.yp_tuning_export(self._h, None, 0))
+        buf = (C.c_int32 * n)()
+        self._chk(self.lib.yp_tuning_export(self._h, buf, n))
+        return list(buf)
+
+    def tuning_import(self, B: int, H: int, W: int, cfgs) -> None:
+        """Install another engine's tile configurations for shape (B,H,W): the next forward of that shape does not tune, and its bf16
+        results equal the exporting engine's bit for bit (same build)."""
+        cfgs = [int(c) for c in cfgs]
+        buf = (C.c_int32 * len(cfgs))(*cfgs)
+        self._chk(self.lib.yp_tuning_import(self._h, int(B), int(H), int(W), buf, len(cfgs)))
+
     def set_nms(self, conf: float = 0.25, iou: float = 0.7) -> None:
         """families v8 / 11: thresholds of the NMS inside the forward (`.predict(conf=, iou=)`)."""
         self._chk(self.lib.yp_set_nms(self._h, float(conf), float(iou)))
@@ -324,6 +338,10 @@ class Engine:
                        out=(t.value, co.value, cc.value))
             self._chk(self.lib.yp_op_kernel(self._h, i, name, 256))
             rec["kernel"] = name.value.decode()
+            cr = C.c_int()
+            self._chk(self.lib.yp_op_input(self._h, i, C.byref(t), C.byref(co), C.byref(cc), C.byref(cr)))
+            rec["in"] = (t.value, co.value, cc.value)
+            rec["c_read"] = cr.value
             ops.append(rec)
         return ops
 

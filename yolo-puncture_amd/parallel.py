@@ -36,3 +36,29 @@ def gather_detections(det_local: torch.Tensor, out: Optional[torch.Tensor] = Non
     else:
         dist.all_gather_into_tensor(out, det_local, group=group)
     return out
+
+
+def sync_tuning(engine, shape: Tuple[int, int, int], frames: Optional[torch.Tensor] = None, group=None, src: int = 0) -> None:
+    """Make every rank run the SAME conv tile configurations for `shape` = (B,H,W): rank `src` tunes (one forward on `frames`,
+    [B,H,W,3] uint8 on its device), its per-op configuration ids are broadcast, the other ranks install them before their first
+    forward. bf16 outputs depend on the tile configuration in the last bit (fp32 summation order), and each rank's autotuner
+    times its own GPU, so without this a frame's detections could depend on which rank it was sharded to. One broadcast of a
+    few hundred int32 per plan, outside the data path. No-op without an initialised process group."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    B, H, W = (int(v) for v in shape)
+    rank = dist.get_rank(group)
+    dev = torch.device("cpu") if dist.get_backend(group) == "gloo" else torch.device("cuda", torch.cuda.current_device())
+    if rank == src:
+        if frames is None:
+            raise ValueError("sync_tuning: the source rank needs frames to tune on")
+        engine.forward(frames)
+        cfgs = engine.tuning_export()
+        n = torch.tensor([len(cfgs)], dtype=torch.int32, device=dev)
+    else:
+        n = torch.zeros(1, dtype=torch.int32, device=dev)
+    dist.broadcast(n, src=src, group=group)
+    buf = torch.tensor(cfgs, dtype=torch.int32, device=dev) if rank == src else torch.zeros(int(n.item()), dtype=torch.int32, device=dev)
+    dist.broadcast(buf, src=src, group=group)
+    if rank != src:
+        engine.tuning_import(B, H, W, buf.cpu().tolist())
