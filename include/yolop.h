@@ -110,16 +110,25 @@ int yp_id_mask_resized(yp_engine* e, int b, const float* coeff_dev, const float*
                        int rw, int64_t* id_out, int32_t* kept_out, int suppress_small, int min_area, void* stream);
 
 /* `results[0].masks.xy[i]` and `get_coord_min_rect_len(...)` on the device (yolo_seg/app.py:101-103, yolo_seg/utils/mask_tools.py:12-22;
- * [U] Masks.xy = masks2segments(strategy="largest"): cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE), the contour with the most
- * points; get_coord_min_rect_len = cv2.minAreaRect of that polygon -> (long side, long/short)). Engine-free. Per mask (one workgroup):
- * bit image of the mask's bounding box in LDS, Moore trace of every blob's outer border, run end points of the longest one, convex
- * hull, rotating calipers.
+ * [U] Masks.xy = masks2segments(strategy): cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE), then "all" (the 8.3.x line the app's
+ * YOLO11 weights need: every contour, concatenated) or "largest" (8.0-8.2: the contour with the most points, the first of them on a tie);
+ * get_coord_min_rect_len = cv2.minAreaRect of that polygon -> (long side, long/short)). Engine-free. Per mask (one workgroup): bit image
+ * of the mask's bounding box in LDS, Moore trace of every blob's outer border, RETR_EXTERNAL by crossing parity (a blob inside a hole of
+ * another blob is skipped), run end points, convex hull, rotating calipers. cv2 is not available to pin this against; the definitions are
+ * written out in yolo-puncture_amd/hostops.py ("Masks.xy") and restated three ways in the tests: a contour starts at its blob's raster-first
+ * pixel and runs down first (a filled rectangle: top-left, bottom-left, bottom-right, top-right); contours are listed bottom-up
+ * (descending raster order of the start pixels).
  *    masks_dev uint8 [n,H,W] (non-zero = set)
+ *    strategy  YP_CONTOURS_LARGEST or YP_CONTOURS_ALL
  *    pts_out   int32 [n,max_pts,2] (x,y) polygon in mask pixels       count_out int32 [n]: number of points; 0 = empty mask;
- *              -1 = bounding box larger than the LDS image (1280x720 fits), -2 = more than max_pts points: use the host path
+ *              -1 = bounding box larger than the LDS image (1280x720 fits), -2 = more than max_pts points / 4096 border starts / 64 outer
+ *              borders: use the host path (hostops.mask_polygon)
+ *    parts_out int32 [n,parts_cap] or NULL: [0] = contours in the list, [1 .. ] = their point counts in list order (as many as fit)
  *    rect_out  double [n,2] = (long side, short side) of the minimum-area rectangle of the polygon (may be NULL) */
-int yp_mask_contours(const uint8_t* masks_dev, int n, int H, int W, int max_pts, int32_t* pts_out, int32_t* count_out,
-                     double* rect_out, void* stream);
+#define YP_CONTOURS_LARGEST 0
+#define YP_CONTOURS_ALL 1
+int yp_mask_contours(const uint8_t* masks_dev, int n, int H, int W, int strategy, int max_pts, int32_t* pts_out, int32_t* count_out,
+                     int32_t* parts_out, int parts_cap, double* rect_out, void* stream);
 
 /* LetterBox on the device (the step before the network inside `.predict`; reference call sites yolo_seg/app.py:86-91,
  * [U] ultralytics LetterBox = cv2.resize INTER_LINEAR + cv2.copyMakeBorder(114)). Engine-free, pure function of its

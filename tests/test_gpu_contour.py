@@ -1,6 +1,8 @@
-"""yp_mask_contours (HIP: bit image in LDS, parallel Moore traces, hull, rotating calipers) against the host restatement of what the
-reference does with a mask per frame (yolo_seg/app.py:101-103: masks.xy[best] -> get_coord_min_rect_len): the polygon is integer work
-and must be identical point for point; the rectangle is float64 and is also checked against an independent brute-force form."""
+"""yp_mask_contours (HIP: bit image in LDS, parallel Moore traces, RETR_EXTERNAL by crossing parity, hull, rotating calipers) against the
+host statement of what the reference does with a mask per frame (yolo_seg/app.py:101-103: masks.xy[best] -> get_coord_min_rect_len):
+hostops.mask_polygon = connected components + hole filling + a reversed Moore trace, itself held to a Suzuki & Abe restatement in
+tests/test_host.py. The polygon is integer work and must be identical point for point, in both masks2segments strategies; the rectangle
+is float64 and is also checked against an independent brute-force form."""
 import numpy as np
 import pytest
 import torch
@@ -84,14 +86,60 @@ def _cases():
     return c
 
 
-@pytest.mark.parametrize("name,mask", _cases(), ids=[n for n, _ in _cases()])
-def test_contour_and_rect_match_host(name, mask):
-    polys, rect = mask_contours_device(torch.from_numpy(mask)[None].cuda(), max_pts=8192)
-    want = hostops.largest_external_contour(mask.astype(bool))
+def _more_cases():
+    c = []
+    m = np.zeros((64, 80), np.uint8)
+    # a ring whose hole holds a blob with a busier border than the ring's own (notches): the old "largest" would have picked the inner blob
+    a = m.copy(); a[4:60, 4:76] = 1; a[12:52, 12:68] = 0; a[20:44, 24:56] = 1
+    a[20, 26:54:3] = 0; a[43, 27:54:3] = 0; a[22:42:3, 24] = 0
+    c.append(("nested_busy_inner", a))
+    # three levels: ring, ring in its hole, blob in that ring's hole - only the outermost is external
+    b = m.copy(); b[2:62, 2:78] = 1; b[8:56, 8:72] = 0; b[14:50, 14:66] = 1; b[20:44, 20:60] = 0; b[28:36, 30:50] = 1
+    c.append(("nested_three_levels", b))
+    # a blob in an OPEN bay is external; several separate blobs around it
+    d = m.copy(); d[10:54, 10:70] = 1; d[18:46, 18:70] = 0; d[26:38, 30:50] = 1; d[2:6, 2:30] = 1; d[58:62, 40:78] = 1; d[30, 74] = 1
+    c.append(("bay_and_fragments", d))
+    # a ring closed only by diagonal links (8-connected foreground / 4-connected background) around a dot, next to a free dot
+    e = m.copy()
+    for y, x in ((10, 20), (11, 19), (12, 18), (13, 17), (14, 18), (15, 19), (16, 20), (15, 21), (14, 22), (13, 23), (12, 22), (11, 21), (13, 20), (13, 40)):
+        e[y, x] = 1
+    c.append(("diagonal_ring", e))
+    # fragmented needle-like mask: a long thin bar broken into pieces of different sizes
+    f = _rot_rect(120, 200, 100.0, 60.0, 80.0, 3.0, 0.4)
+    f[:, 60:64] = 0; f[:, 118:121] = 0; f[:, 150:152] = 0
+    c.append(("fragmented_bar", f.astype(np.uint8)))
+    # equal point counts: "largest" takes the first of the bottom-up list, i.e. the LOWER of two identical squares
+    g = m.copy(); g[5:15, 5:15] = 1; g[40:50, 30:40] = 1
+    c.append(("tie_two_squares", g))
+    # more than 64 outer borders (the table's size) in the segmented path: "largest" goes by rounds - the busy blob C inside ring B inside
+    # ring A must be dropped (it lies inside TWO borders: parity per border, not summed), then B (inside A), leaving A; dots all around
+    h = m.copy(); h[::3, ::3] = 1; h[8:60, 10:74] = 0
+    h[10:58, 12:72] = 1; h[14:54, 16:68] = 0; h[18:50, 20:64] = 1; h[22:46, 24:60] = 0; h[28:40, 30:54] = 1
+    h[28, 32:52:3] = 0; h[39, 31:52:3] = 0
+    c.append(("many_dots_nested", h))
+    return c
+
+
+ALL = _cases() + _more_cases()
+
+
+@pytest.mark.parametrize("strategy", ["all", "largest"])
+@pytest.mark.parametrize("name,mask", ALL, ids=[n for n, _ in ALL])
+def test_contour_and_rect_match_host(name, mask, strategy):
+    polys, rect, parts = mask_contours_device(torch.from_numpy(mask)[None].cuda(), max_pts=8192, strategy=strategy, want_parts=True)
+    want = hostops.mask_polygon(mask.astype(bool), strategy)
+    ext = hostops.external_contours(mask.astype(bool))
     got = polys[0]
+    if name in ("dots", "many_dots_nested") and strategy == "all":      # hundreds of isolated pixels: more outer borders than the device lists (64) -> declined, not wrong
+        assert got is None
+        return
     assert got is not None, "the device path must handle this mask"
     assert got.dtype == np.int32 and got.shape == want.shape, (got.shape, want.shape)
     assert np.array_equal(got, want)                                       # integer work: identical, point for point, same order
+    if strategy == "all":
+        assert parts[0] == [len(c) for c in ext]                            # the list's contours, bottom-up
+    else:
+        assert parts[0] == ([len(want)] if len(want) else [])
     wl, ww = hostops.min_area_rect_size(want) if want.shape[0] else (0.0, 0.0)
     assert rect[0, 0] == pytest.approx(wl, rel=1e-12, abs=1e-12) and rect[0, 1] == pytest.approx(ww, rel=1e-12, abs=1e-9)
     if want.shape[0] >= 3:
@@ -99,11 +147,44 @@ def test_contour_and_rect_match_host(name, mask):
         assert rect[0, 0] == pytest.approx(bl, rel=1e-9, abs=1e-9) and rect[0, 1] == pytest.approx(bw, rel=1e-9, abs=1e-7)
 
 
+def test_nested_blob_is_not_external():
+    """RETR_EXTERNAL: the busy blob inside the ring's hole has more run end points than the ring's four corners, and on its own it IS the
+    contour - inside the hole it must be skipped by both strategies (yolo_seg/app.py:101-103 would otherwise measure the wrong shaft)."""
+    name, a = _more_cases()[0]
+    inner = a.copy(); inner[:12] = 0; inner[52:] = 0; inner[:, :12] = 0; inner[:, 68:] = 0
+    p_in, _ = mask_contours_device(torch.from_numpy(inner)[None].cuda(), strategy="largest")
+    assert len(p_in[0]) > 20
+    for strategy in ("largest", "all"):
+        p, rect = mask_contours_device(torch.from_numpy(a)[None].cuda(), strategy=strategy)
+        assert p[0].tolist() == [[4, 4], [4, 59], [75, 59], [75, 4]]
+        assert rect[0, 0] == pytest.approx(71.0) and rect[0, 1] == pytest.approx(55.0)
+    # the tie rule of "largest": first of the bottom-up list
+    g = _more_cases()[5][1]
+    p, _ = mask_contours_device(torch.from_numpy(g)[None].cuda(), strategy="largest")
+    assert p[0].tolist() == [[30, 40], [30, 49], [39, 49], [39, 40]]
+
+
+def test_noise_mask_one_lane_path():
+    """More than 1024 border starts: one lane per candidate walks its whole border; "largest" then tests its winner against the borders that
+    start before it (rounds), "all" declines beyond 64 outer borders."""
+    rng = np.random.default_rng(3)
+    m = (rng.random((200, 300)) < 0.5).astype(np.uint8)
+    m[40:160, 60:240] = 1; m[60:140, 90:210] = 0; m[80:120, 120:180] = (rng.random((40, 60)) < 0.62)     # a noisy blob inside a ring inside noise
+    polys, rect = mask_contours_device(torch.from_numpy(m)[None].cuda(), strategy="largest")
+    want = hostops.mask_polygon(m.astype(bool), "largest")
+    assert polys[0] is not None and np.array_equal(polys[0], want)
+    polys, _ = mask_contours_device(torch.from_numpy(m)[None].cuda(), strategy="all")
+    assert polys[0] is None
+
+
 def test_batch_of_masks_and_fallback_codes():
     ms = np.stack([_blobs(120, 160, s) for s in range(5)] + [np.zeros((120, 160), np.uint8)])
     polys, rect = mask_contours_device(torch.from_numpy(ms).cuda())
     for i in range(6):
-        assert np.array_equal(polys[i], hostops.largest_external_contour(ms[i].astype(bool)))
+        assert np.array_equal(polys[i], hostops.mask_polygon(ms[i].astype(bool), "all"))
+    polys_l, _ = mask_contours_device(torch.from_numpy(ms).cuda(), strategy="largest")
+    for i in range(6):
+        assert np.array_equal(polys_l[i], hostops.largest_external_contour(ms[i].astype(bool)))
     assert polys[5].shape == (0, 2) and rect[5, 0] == 0.0
     # too many points for the caller's buffer -> the device pass declines (host path takes over in Masks.xy)
     polys, _ = mask_contours_device(torch.from_numpy((np.indices((64, 80)).sum(0) % 2).astype(np.uint8))[None].cuda(), max_pts=16)
@@ -145,7 +226,7 @@ def test_hole_border_with_local_tops_is_not_a_contour():
     m2 = m.copy()
     m2[28:36, 40:80] = 1                       # a blob inside the hole
     m2[24:28, 44:76:4] = 1                     # ... with spikes of its own (outer-border local tops of the nested blob)
-    polys, rect = mask_contours_device(torch.from_numpy(np.stack([m, m2])).cuda())
+    polys, rect = mask_contours_device(torch.from_numpy(np.stack([m, m2])).cuda(), strategy="largest")
     for i, mm in enumerate((m, m2)):
         want = hostops.largest_external_contour(mm.astype(bool))
         assert polys[i] is not None and np.array_equal(polys[i], want), (i, len(polys[i]), len(want))

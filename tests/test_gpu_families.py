@@ -66,14 +66,20 @@ def test_nms_rows_match_oracle(family, variant, conf, nc):
     st, im, taps, ref, eng, out = _run(family, variant, "fp32", (2, 96, 128), conf, nc=nc)
     ref64 = SegOracle(st, family, variant, nc, "fp64").forward(im, conf=conf)
     det, idx, cf = out["det"].cpu(), out["idx"].cpu().long(), out["coeff"].cpu()
+    total_rows = 0
     for b in range(2):
         want, widx, wcf = ref["det"][b], ref["idx"][b], ref["coeff"][b]
         n = want.shape[0]
         ncand = int((ref["scores"][b].max(1).values > conf).sum())
-        assert n >= 5 and n < ncand, "the case must make NMS work"
+        if nc == 80:
+            assert n >= 5 and n < ncand, "the case must make NMS work"
         got_n = int((idx[b] >= 0).sum())
         assert got_n == n, (got_n, n)
         assert bool((idx[b, n:] == -1).all()) and float(det[b, n:].abs().max()) == 0.0
+        total_rows += n
+        if n < 3:
+            assert torch.equal(idx[b, :n], widx) and torch.equal(det[b, :n, 5], want[:, 5])      # (1 / 3 classes: an image may keep next to nothing)
+            continue
         s = want[:, 4]
         gap = (s[:-1] - s[1:]).abs()
         clear = torch.ones(n, dtype=torch.bool)
@@ -88,6 +94,7 @@ def test_nms_rows_match_oracle(family, variant, conf, nc):
         assert_within_noise_floor(f"[{b}] NMS rows: boxes [px]", det[b, :n, :4][same], want[:, :4][same], w64[:, :4][same], 1e-3)
         assert_within_noise_floor(f"[{b}] NMS rows: scores", det[b, :n, 4][same], want[:, 4][same], w64[:, 4][same], 1e-3)
         assert_within_noise_floor(f"[{b}] NMS rows: mask coefficients", cf[b, :n][same], wcf[same], c64[same], 1e-3)
+    assert total_rows >= 5
     pr = nchw_to_nhwc(ref["proto"])
     assert rel_err(eng.proto(), pr) < 1e-4
     # the thresholds live in device memory: a higher conf on the same engine returns the prefix of rows above it (NMS is monotone)

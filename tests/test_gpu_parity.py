@@ -374,7 +374,7 @@ def test_tuning_export_import_reproduces_bits():
         assert torch.equal(out[k], ref[k]), k
     assert torch.equal(b.read_tensor(b.find_tensor("model.23.one2one_cv3.0.2")), logits_a)
     bad = list(cfgs)
-    j = next(i for i, o in enumerate(ops) if o["kind"] == "conv" and o["kernel"] != "-" and cfgs[i] >= 100)
+    j = next(i for i, c in enumerate(cfgs) if 300 <= c < 500 or 600 <= c < 900)      # a plain (never fused) tunable conv
     bad[j] = 999                                             # conv_ks id beyond its table
     with pytest.raises(YolopError):
         b.tuning_import(*shape, bad)

@@ -101,12 +101,16 @@ def test_scale_boxes_matches_oracle():
 
 
 def test_contours():
+    # cv2's order for an outer border: from the raster-first pixel DOWN first (top-left, bottom-left, bottom-right, top-right)
     m = np.zeros((12, 14), bool)
     m[3:8, 4:11] = True
-    assert hostops.largest_external_contour(m).tolist() == [[4, 3], [10, 3], [10, 7], [4, 7]]
-    m[0, 0] = True                                  # a second, smaller blob is ignored ("largest")
+    assert hostops.largest_external_contour(m).tolist() == [[4, 3], [4, 7], [10, 7], [10, 3]]
+    m[0, 0] = True                                  # a second, smaller blob: ignored by "largest", listed LAST by "all" (bottom-up order)
     assert hostops.largest_external_contour(m).shape[0] == 4
+    assert hostops.mask_polygon(m, "all").tolist() == [[4, 3], [4, 7], [10, 7], [10, 3], [0, 0]]
+    assert [c.tolist() for c in hostops.external_contours(m)] == [[[4, 3], [4, 7], [10, 7], [10, 3]], [[0, 0]]]
     assert hostops.largest_external_contour(np.zeros((5, 5), bool)).shape == (0, 2)
+    assert hostops.mask_polygon(np.zeros((5, 5), bool), "all").shape == (0, 2)
     one = np.zeros((5, 5), bool)
     one[2, 3] = True
     assert hostops.largest_external_contour(one).tolist() == [[3, 2]]
@@ -114,7 +118,52 @@ def test_contours():
     ring = np.zeros((9, 9), bool)
     ring[1:8, 1:8] = True
     ring[3:6, 3:6] = False
-    assert hostops.largest_external_contour(ring).tolist() == [[1, 1], [7, 1], [7, 7], [1, 7]]
+    assert hostops.largest_external_contour(ring).tolist() == [[1, 1], [1, 7], [7, 7], [7, 1]]
+    # RETR_EXTERNAL: a blob inside the hole of another blob is not an external contour - even when its border has more points than the
+    # ring's four corners ("largest" must not pick it), and "all" must not list it
+    nest = np.zeros((20, 24), bool)
+    nest[1:19, 1:23] = True
+    nest[4:16, 4:20] = False
+    nest[7:13, 8:16] = True
+    nest[7, 9] = nest[12, 14] = nest[9, 8] = False   # notches: the inner blob's outer border keeps many more points than 4
+    inner = nest.copy()
+    inner[:4] = inner[16:] = False
+    inner[:, :4] = inner[:, 20:] = False
+    assert hostops.largest_external_contour(inner).shape[0] > 4          # on its own the inner blob is a contour with many points
+    assert hostops.largest_external_contour(nest).tolist() == [[1, 1], [1, 18], [22, 18], [22, 1]]
+    assert hostops.mask_polygon(nest, "all").tolist() == [[1, 1], [1, 18], [22, 18], [22, 1]]
+    # ... but a blob in an OPEN bay is external (the bay's background reaches the frame)
+    bay = nest.copy()
+    bay[8:12, 20:23] = False                         # cut the ring open on the right
+    assert len(hostops.external_contours(bay)) == 2
+    # a ring closed only by diagonal links still encloses (foreground 8-connected, background 4-connected)
+    dia = np.zeros((9, 9), bool)
+    for y, x in ((1, 4), (2, 3), (3, 2), (4, 1), (5, 2), (6, 3), (7, 4), (6, 5), (5, 6), (4, 7), (3, 6), (2, 5), (4, 4)):
+        dia[y, x] = True
+    assert len(hostops.external_contours(dia)) == 1
+
+
+def test_contours_three_statements_agree():
+    """hostops.external_contours (connected components + hole filling + a reversed Moore trace) against tests/suzuki_abe.py (Suzuki &
+    Abe's raster scan with +/-NBD labels and the external mode's "last labelled pixel on the row is positive" rule, as cv2 runs it):
+    same contours, same order, same points, on random masks of every density (nested blobs, one-pixel-wide rings, diagonal links)."""
+    from suzuki_abe import find_contours_external_simple
+    rng = np.random.default_rng(7)
+    n_nested = 0
+    for it in range(600):
+        H, W = int(rng.integers(3, 15)), int(rng.integers(3, 17))
+        m = rng.random((H, W)) < rng.choice([0.15, 0.35, 0.5, 0.65, 0.8])
+        if it % 5 == 0 and H >= 9 and W >= 9:          # structure: a ring with something in its hole
+            m[:] = False
+            m[1:H - 1, 1:W - 1] = True
+            m[2 + it % 2:H - 2, 2:W - 2 - it % 3] = rng.random((H - 4 - it % 2, W - 4 - it % 3)) < 0.3
+        a, b = hostops.external_contours(m), find_contours_external_simple(m)
+        assert len(a) == len(b), (it, m.astype(int))
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), (it, m.astype(int), x.tolist(), y.tolist())
+        from scipy import ndimage
+        n_nested += ndimage.label(m, structure=np.ones((3, 3)))[1] - len(a)
+    assert n_nested > 20           # the sample did contain enclosed blobs
 
 
 def test_sources_and_results_surface():

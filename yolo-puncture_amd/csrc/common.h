@@ -347,7 +347,8 @@ struct MaskParams {
 hipError_t launch_masks(const MaskParams& p, int dtype, hipStream_t st);
 size_t masks_workspace_bytes(const MaskParams& p);
 hipError_t contour_read_clocks(unsigned long long* out12);
-hipError_t launch_contours(const uint8_t* masks, int n, int H, int W, int max_pts, int32_t* pts, int32_t* count, double* rect, hipStream_t st);
+hipError_t launch_contours(const uint8_t* masks, int n, int H, int W, int strategy, int max_pts, int32_t* pts, int32_t* count, int32_t* parts, int parts_cap,
+                           double* rect, hipStream_t st);
 
 // host-side float -> bf16 (round to nearest even), as the device's v_cvt_pk_bf16_f32
 static inline uint16_t f2bf(float f) {

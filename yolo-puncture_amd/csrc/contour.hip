@@ -1,6 +1,7 @@
 // Masks.xy + the shaft-length rectangle on the GPU: what the reference's video loop does with every frame's best mask,
-//     coord_xy = results[0].masks.xy[best]                 (yolo_seg/app.py:101; [U] masks2segments(strategy="largest") = cv2.findContours
-//                                                            RETR_EXTERNAL / CHAIN_APPROX_SIMPLE, the contour with the most points)
+//     coord_xy = results[0].masks.xy[best]                 (yolo_seg/app.py:101; [U] masks2segments = cv2.findContours RETR_EXTERNAL /
+//                                                            CHAIN_APPROX_SIMPLE, then strategy "all" (8.3.x: every contour, concatenated)
+//                                                            or "largest" (8.0-8.2: the contour with the most points))
 //     rect_len, ratio = get_coord_min_rect_len(coord_xy)    (yolo_seg/app.py:102-103; yolo_seg/utils/mask_tools.py:12-22 = cv2.minAreaRect)
 // without the full-resolution mask ever leaving HBM. A pre-pass finds the bounding boxes (32 workgroups per mask), then one workgroup per mask:
 //   1. bit image of the box in LDS (one zero word / row around it; masks are zero outside their detection box)
@@ -13,18 +14,27 @@
 //         candidate (a hole border) is dropped; point counts from the segments + the joints
 //      b. otherwise (noise masks): one lane per candidate walks its whole border; a walk that meets a pixel earlier in raster order than
 //         its start is not a blob's outer border from its first pixel and is dropped - no connected-component labelling either way.
-//      The survivors are exactly the traces hostops.largest_external_contour makes; the one with the most points wins (ties: first in
-//      raster order)
-//   4. the winner's list is assembled by parallel copies (a serial re-trace only when a list overflowed); per-column min/max of the points
-//      -> Andrew's monotone chain on at most 2 points per column (exact integer cross products, both chains at once) -> rotating calipers
-//      over the hull edges in float64.
+//      The survivors are the outer borders of the 8-connected blobs.
+//   3c. RETR_EXTERNAL: with two or more outer borders, one that lies INSIDE another (a blob in a hole of another blob) is not external.
+//      Decided by crossing parity: the walkers go round once more and count, for every border start q, the unit moves that cross the
+//      rightward ray from q (half-open rule on the pixel-centre polygon; a start pixel never lies on another blob's polygon); q is nested
+//      iff some other outer border crosses its ray an odd number of times. One blob (the needle's usual mask) skips all of this.
+//   4. order: contours are listed bottom-up (descending raster order of their start pixels - the order cv2 hands them back in);
+//      "largest" keeps the one with the most points (first in that order on a tie), "all" keeps every one. Lists are assembled by parallel
+//      copies (a serial re-trace only when a list overflowed), each turned round from the start pixel (the walkers go clockwise, cv2's
+//      outer borders run the other way: down first); per-column min/max of all points -> Andrew's monotone chain on at most 2 points per
+//      column (exact integer cross products, both chains at once) -> rotating calipers over the hull edges in float64.
+// The same definitions, stated on the host: hostops.external_contours / mask_polygon (connected components + hole filling); a third,
+// independent statement (Suzuki & Abe's raster labelling as cv2 runs it) checks both in tests/.
 #include "common.h"
 #include <cstdio>
 
 namespace yp {
 
 constexpr int CT_THREADS = 1024;
-constexpr int CT_MAXCAND = 6144;
+constexpr int CT_MAXCAND = 4096;            // candidate starts (cand[] behind the bit image); a multiple of CT_THREADS: the one-lane path keeps its
+                                            // candidates' results in registers, CT_MAXCAND / CT_THREADS per thread
+constexpr int CT_NLMAX = 64;                // outer borders that take part in the nesting test / the "all" list (more: the host path)
 constexpr int CT_BITMAP_BYTES = 126 * 1024;        // a whole 1280x720 frame fits (722 rows x 43 words)
 constexpr int CT_MAXCOL = 2048;            // hull column tables
 
@@ -33,7 +43,10 @@ struct ContourParams {
     int n, H, W;
     int max_pts;
     int32_t* pts;              // [n][max_pts][2] (x, y) of the winning contour's run end points
-    int32_t* count;            // [n] number of points (0: empty mask ; -1: bounding box too large for the LDS image ; -2: more than max_pts points / candidates)
+    int32_t* count;            // [n] number of points (0: empty mask ; -1: bounding box too large for the LDS image ; -2: more than max_pts points / candidates / contours)
+    int strategy;              // 0 = "largest", 1 = "all"
+    int32_t* parts;            // [n][parts_cap] or null: [0] = number of external contours in the list, [1..] = their point counts in list order
+    int parts_cap;
     double* rect;              // [n][2] (long side, short side) of the minimum-area rectangle of those points, or null
     int boxg;                  // workgroups per mask of the bounding-box pre-pass (their partial boxes sit at the head of the mask's `pts`)
 };
@@ -182,6 +195,47 @@ __device__ void trace_segment(const Bitmap& bm, const unsigned* cbm, int bw, int
     }
 }
 
+// Crossing parity of a border (SEG: of one segment of it) against up to 64 query pixels: bit q of the result toggles for every unit move
+// (y1,x1) -> (y2,x2) of the walk that crosses the rightward ray from query q under the half-open rule of the crossing-number test -
+// (y1 > qy) != (y2 > qy), and the end point on row qy lies right of qx (moves are unit steps, so the other end point is on row qy + 1).
+// Summed over a closed border the bit says whether q lies inside the polygon through the border's pixel centres; pieces walked twice
+// (one-pixel-wide parts) cancel. Same walk as trace_segment / moore_trace.
+template <bool SEG>
+__device__ unsigned long long walk_parity(const Bitmap& bm, const unsigned* cbm, int bw, int sy, int sx, int max_steps, const int* qy, const int* qx, int nq) {
+    const int start_lin = sy * bw + sx;
+    int cy = sy, cx = sx, rb = sy * bm.pitch, lin = start_lin;
+    unsigned long long tog = 0ull;
+    unsigned nbm = bm.ring(rb, cx);
+    if (nbm == 0) return 0ull;
+    int nd = (6 + __builtin_ctz(((nbm >> 6) | (nbm << 2)) & 0xffu)) & 7;
+    const int start_d = nd;
+    auto cross = [&](int y1, int x1, int y2, int x2) {
+        if (y1 == y2) return;
+        const int ylo = min(y1, y2), xa = (y1 < y2) ? x1 : x2;      // the end point on the upper row (the row a query must be on)
+        for (int q = 0; q < nq; ++q)
+            if (qy[q] == ylo && xa > qx[q]) tog ^= 1ull << q;
+    };
+    {
+        const int dy = c_dy(nd), dx = c_dx(nd);
+        cross(cy, cx, cy + dy, cx + dx);
+        cy += dy; cx += dx; rb += dy * bm.pitch; lin += dy * bw + dx;
+    }
+    int d = (nd + 6 - (nd & 1)) & 7;
+    for (int step = 1; step < max_steps; ++step) {
+        nbm = bm.ring(rb, cx);
+        nd = (d + __builtin_ctz(((nbm >> d) | (nbm << (8 - d))) & 0xffu)) & 7;
+        if (SEG) {
+            const unsigned cw = cbm[rb + bm.pitch + 1 + (cx >> 5)];
+            if (((cw >> (cx & 31)) & 1u) && nd == ((6 + __builtin_ctz(((nbm >> 6) | (nbm << 2)) & 0xffu)) & 7)) return tog;
+        } else if (lin == start_lin && nd == start_d) return tog;
+        const int dy = c_dy(nd), dx = c_dx(nd);
+        cross(cy, cx, cy + dy, cx + dx);
+        cy += dy; cx += dx; rb += dy * bm.pitch; lin += dy * bw + dx;
+        d = (nd + 6 - (nd & 1)) & 7;
+    }
+    return tog;
+}
+
 // Bounding-box pre-pass: CT_BOXG workgroups per mask, each over a contiguous 1/CT_BOXG of the pixels; the partial boxes go to the head
 // of the mask's `pts` region (consumed by contour_kernel before it writes anything there). One workgroup scanning a 1280x720 mask
 // alone took 93 us of the 600-us kernel.
@@ -220,12 +274,10 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ int s_box[4];                 // x0, y0, x1, y1 (inclusive)
     __shared__ int s_ncand;
-    __shared__ unsigned long long s_best;    // (points << 32) | ~start_lin
     __shared__ int s_np, s_nhull;
-    __shared__ int s_win_slot, s_win_stored;  // the winner's slot (-1: it had none) and the points it stored there
     const int mi = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint8_t* M = p.masks + (size_t)mi * p.H * p.W;
-    if (tid == 0) { s_box[0] = p.W; s_box[1] = p.H; s_box[2] = -1; s_box[3] = -1; s_ncand = 0; s_best = 0ull; s_np = 0; s_nhull = 0; s_win_slot = -1; s_win_stored = 0; }
+    if (tid == 0) { s_box[0] = p.W; s_box[1] = p.H; s_box[2] = -1; s_box[3] = -1; s_ncand = 0; s_np = 0; s_nhull = 0; }
     __syncthreads();
     CT_STAMP(0);
     // ---- 1a. bounding box: the partial boxes of contour_bbox_kernel ---------------------------------------------------------
@@ -237,13 +289,13 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     __syncthreads();
     const int bx0 = s_box[0], by0 = s_box[1], bx1 = s_box[2], by1 = s_box[3];
     if (bx1 < 0) {                            // empty mask
-        if (tid == 0) { p.count[mi] = 0; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
+        if (tid == 0) { p.count[mi] = 0; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } if (p.parts) p.parts[(size_t)mi * p.parts_cap] = 0; }
         return;
     }
     const int bw = bx1 - bx0 + 1, bh = by1 - by0 + 1;
     const int pitch = (bw + 31) / 32 + 3;     // one zero word left, one right, one for the 64-bit window's overrun
     if ((size_t)(bh + 2) * pitch * 4 > (size_t)CT_BITMAP_BYTES || bw > CT_MAXCOL) {
-        if (tid == 0) { p.count[mi] = -1; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
+        if (tid == 0) { p.count[mi] = -1; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } if (p.parts) p.parts[(size_t)mi * p.parts_cap] = 0; }
         return;
     }
     unsigned* bmw = (unsigned*)smem;
@@ -290,7 +342,7 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     __syncthreads();
     const int ncand = s_ncand;
     if (ncand > CT_MAXCAND) {
-        if (tid == 0) { p.count[mi] = -2; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
+        if (tid == 0) { p.count[mi] = -2; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } if (p.parts) p.parts[(size_t)mi * p.parts_cap] = 0; }
         return;
     }
     CT_STAMP(3);
@@ -298,29 +350,49 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     // ---- 3. trace every candidate -------------------------------------------------------------------------------------------
     const int max_steps = 4 * bh * bw + 8;
     int32_t* out = p.pts + (size_t)mi * p.max_pts * 2;
+    constexpr int CPT = CT_MAXCAND / CT_THREADS;  // one-lane path: candidate tid + i * CT_THREADS lives in my_np[i] = (points << 1 | start point kept), 0 = dropped
+    static_assert(CPT * CT_THREADS == CT_MAXCAND, "candidates per thread");
+    int my_np[CPT];
     // the list's head (region 0) takes the result; regions 1 .. nslots behind it are the candidates' own lists
     const int slot_cap = p.max_pts >= 8 * CT_SLOT_PTS ? CT_SLOT_PTS : p.max_pts / 8;
     const int nslots = slot_cap >= 8 ? min(CT_MAXSLOTS, p.max_pts / slot_cap - 1) : 0;
+    // outer borders found (their leaders): candidate index, points, start point kept, start pixel, external?
+    __shared__ int s_nl, s_no, s_total;
+    __shared__ int l_k[CT_NLMAX], l_np[CT_NLMAX], l_sk[CT_NLMAX], l_y[CT_NLMAX], l_x[CT_NLMAX], l_ext[CT_NLMAX], l_ord[CT_NLMAX], l_base[CT_NLMAX];
+    __shared__ unsigned long long l_par[CT_NLMAX];
+    __shared__ int s_stored[CT_MAXSLOTS];         // one-lane path: points a candidate with a slot stored in it
+    __shared__ unsigned long long s_key;          // "largest" among more than CT_NLMAX borders: the round's best (points, start, candidate)
+    __shared__ int s_in, s_qw[2];                 // ... is it inside another border? its start pixel (y, x)
+    if (tid == 0) { s_nl = 0; s_no = 0; s_total = 0; }
+    if (tid < CT_NLMAX) l_par[tid] = 0ull;
+    auto decline = [&](int code) {                // (uniform: every thread takes the same branch)
+        if (tid == 0) { p.count[mi] = code; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } if (p.parts) p.parts[(size_t)mi * p.parts_cap] = 0; }
+    };
     // ---- 3a. segmented trace (see trace_segment): needs a second bit image (the candidate pixels) + per-candidate tables in LDS ----
     constexpr int CT_SEGMAX = 1024;
     const size_t bm_bytes = (((size_t)(bh + 2) * pitch * 4) + 15) & ~(size_t)15;
-    bool seg_done = false;
-    if (ncand <= CT_SEGMAX && nslots > 0 && 2 * bm_bytes + (size_t)CT_SEGMAX * 28 <= (size_t)CT_BITMAP_BYTES) {
-        __shared__ int s_cyc_len, s_seg_ok;
-        unsigned* cbm = (unsigned*)(smem + bm_bytes);
-        int* nxt = (int*)(smem + 2 * bm_bytes);                  // successor candidate (index into the sorted list), -1 = none
-        int* nkp = nxt + CT_SEGMAX;                              // interior kept points of the segment
-        int* nmv = nkp + CT_SEGMAX;                              // moves of the segment (later: output offset of the segment's points)
-        int* mvs = nmv + CT_SEGMAX;                              // first move | last move << 4
-        int* cyc = mvs + CT_SEGMAX;                              // the winner's segments in border order
-        int* jkp = cyc + CT_SEGMAX;                              // winner: 1 if the joint point at the segment's start is kept
-        int* mnl = jkp + CT_SEGMAX;                              // raster-first pixel the segment visits
+    const bool seg_mode = ncand <= CT_SEGMAX && nslots > 0 && 2 * bm_bytes + (size_t)CT_SEGMAX * 32 <= (size_t)CT_BITMAP_BYTES;
+    unsigned* cbm = (unsigned*)(smem + bm_bytes);
+    int* nxt = (int*)(smem + 2 * bm_bytes);                  // successor candidate (index into the sorted list), -1 = none
+    int* nkp = nxt + CT_SEGMAX;                              // interior kept points of the segment
+    int* nmv = nkp + CT_SEGMAX;                              // moves of the segment (later: output offset of the segment's points)
+    int* mvs = nmv + CT_SEGMAX;                              // first move | last move << 4
+    int* cyc = mvs + CT_SEGMAX;                              // assembly: the contour's segments in border order
+    int* jkp = cyc + CT_SEGMAX;                              // assembly: 1 if the joint point at the segment's start is kept (before: leader -> slot)
+    int* mnl = jkp + CT_SEGMAX;                              // raster-first pixel the segment visits
+    int* bid = mnl + CT_SEGMAX;                              // leader (candidate index) of the outer border the segment lies on, -1 = none
+    auto find = [&](int lin) {                               // index of a candidate pixel in the sorted list (segmented path)
+        int lo = 0, hi = ncand - 1;
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (cand[mid] < lin) lo = mid + 1; else hi = mid; }
+        return cand[lo] == lin ? lo : -1;
+    };
+    __syncthreads();
+    if (seg_mode) {
         // sort the candidates by raster position (bitonic over the next power of two; pads = INT_MAX)
         int n2 = 1;
         while (n2 < ncand) n2 <<= 1;
         for (int i = ncand + tid; i < n2; i += CT_THREADS) cand[i] = 0x7fffffff;
         for (int i = tid; i < (int)(bm_bytes / 4); i += CT_THREADS) cbm[i] = 0u;
-        if (tid == 0) { s_cyc_len = 0; s_seg_ok = 1; }
         __syncthreads();
         for (int k2 = 2; k2 <= n2; k2 <<= 1)
             for (int j = k2 >> 1; j > 0; j >>= 1) {
@@ -339,11 +411,6 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
             atomicOr(&cbm[(size_t)(y + 1) * pitch + 1 + (x >> 5)], 1u << (x & 31));
         }
         __syncthreads();
-        auto find = [&](int lin) {                                // index of a candidate pixel in the sorted list
-            int lo = 0, hi = ncand - 1;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (cand[mid] < lin) lo = mid + 1; else hi = mid; }
-            return cand[lo] == lin ? lo : -1;
-        };
         for (int k = tid; k < ncand; k += CT_THREADS) {           // (ncand <= CT_THREADS: one segment per thread)
             const int lin = cand[k];
             const int sy = lin / bw, sx = lin - sy * bw;
@@ -370,7 +437,10 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
             } while (j != k && ++len < ncand);
             // a border counts from its raster-first PIXEL only (as the one-lane trace drops a walk that meets an earlier pixel): a hole
             // border whose first pixel is no local top has candidates but no survivor
-            if (!ok || j != k || lead != k || cmin != cand[k]) continue;
+            const bool valid = ok && j == k && cmin == cand[lead];
+            bid[k] = valid ? lead : -1;
+            cyc[k] = 0;
+            if (!valid || lead != k) continue;
             const int pj = [&] { int q = k; while (nxt[q] != k) q = nxt[q]; return q; }();    // the segment that ends at the leader
             const int start_kept = (((mvs[pj] >> 4) & 15) != (mvs[k] & 15)) ? 1 : 0;
             int np;
@@ -378,49 +448,215 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
             else if (moves <= 2) np = moves;                       // _compress keeps everything
             else np = kept > 0 ? kept : 1;
             const int sk = (moves <= 2) ? 1 : start_kept;
-            atomicMax(&s_best, ((unsigned long long)(unsigned)np << 32) | ((unsigned long long)(0x7fffffffu - (unsigned)cand[k]) << 1) | (unsigned)sk);
+            cyc[k] = (np << 1) | sk;                               // (leaders only; the table below holds the first CT_NLMAX of them)
+            const int li = atomicAdd(&s_nl, 1);
+            if (li < CT_NLMAX) {
+                l_k[li] = k; l_np[li] = np; l_sk[li] = sk; l_y[li] = cand[k] / bw; l_x[li] = cand[k] % bw; l_ext[li] = 1;
+                jkp[k] = li;
+            }
         }
         __syncthreads();
-        CT_STAMP(4);
-        const unsigned long long bestq = s_best;
-        const int npq = (int)(bestq >> 32);
-        if (npq > p.max_pts || npq <= 0) {
-            if (tid == 0) { p.count[mi] = npq > 0 ? -2 : 0; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
-            return;
-        }
-        const int linq = (int)(0x7fffffffu - (unsigned)((bestq & 0xffffffffull) >> 1));
-        const int rotq = (int)(bestq & 1ull);
-        if (tid == 0) {
-            // the winner's segments in order with the output offset of their points; anything that does not fit the lists -> serial trace
-            const int kb = find(linq);
-            int off = rotq, len = 0, j = kb, moves = 0;
-            bool ok = kb >= 0 && npq <= slot_cap;
-            while (ok) {
-                if (j >= nslots || nkp[j] > slot_cap) { ok = false; break; }
-                const int jn = nxt[j];
-                int joint = 0;
-                if (j != kb) {                                     // the joint point at this segment's start
-                    int q = cyc[len - 1];
-                    joint = (((mvs[q] >> 4) & 15) != (mvs[j] & 15)) ? 1 : 0;
+        const int nl = s_nl;
+        if (nl > CT_NLMAX) {
+            if (p.strategy == 1) { decline(-2); return; }
+            // "largest" among more borders than the table holds: take the best, test IT against every other outer border's segments, drop
+            // it if it is nested, again
+            bool found = false;
+            for (int round = 0; round < 16 && !found; ++round) {
+                if (tid == 0) { s_key = 0ull; s_in = 0; }
+                __syncthreads();
+                for (int k = tid; k < ncand; k += CT_THREADS)
+                    if (cyc[k]) atomicMax(&s_key, ((unsigned long long)(unsigned)(cyc[k] >> 1) << 40) | ((unsigned long long)(unsigned)cand[k] << 16) | (unsigned long long)k);
+                __syncthreads();
+                const unsigned long long key = s_key;
+                const int kw = (int)(key & 0xffffull), lw = (int)((key >> 16) & 0xffffffull);
+                if (tid == 0) { s_qw[0] = lw / bw; s_qw[1] = lw % bw; }
+                __syncthreads();
+                for (int k = tid; k < ncand; k += CT_THREADS) mnl[k] = 0;      // (free since the cycles were resolved) parity per border, at its leader
+                __syncthreads();
+                for (int k = tid; k < ncand; k += CT_THREADS) {
+                    if (bid[k] < 0 || bid[k] == kw) continue;
+                    const int lin = cand[k];
+                    if (walk_parity<true>(bm, cbm, bw, lin / bw, lin % bw, max_steps, &s_qw[0], &s_qw[1], 1) & 1ull) atomicXor(&mnl[bid[k]], 1);
                 }
-                jkp[j] = joint;
-                off += joint;
-                moves += nmv[j];
-                cyc[len++] = j;
-                const int myoff = off;
-                off += nkp[j];
-                nmv[j] = myoff;                                    // (moves are no longer needed: the slot becomes the offset)
-                j = jn;
-                if (j == kb) break;
-                if (len >= ncand) { ok = false; break; }
+                __syncthreads();
+                for (int k = tid; k < ncand; k += CT_THREADS)
+                    if (mnl[k]) s_in = 1;
+                __syncthreads();
+                if (s_in == 0) {
+                    found = true;
+                    if (tid == 0) { l_k[0] = kw; l_np[0] = cyc[kw] >> 1; l_sk[0] = cyc[kw] & 1; l_y[0] = s_qw[0]; l_x[0] = s_qw[1]; l_ext[0] = 1; s_nl = 1; }
+                } else if (tid == 0) cyc[kw] = 0;
+                __syncthreads();
             }
-            if (ok && (moves <= 2 || off != npq)) ok = false;      // tiny borders and any disagreement go the serial way
-            s_seg_ok = ok ? 1 : 0;
+            if (!found) { decline(-2); return; }
+        } else if (nl >= 2) {                                      // 3c. which outer borders lie inside another one?
+            for (int k = tid; k < ncand; k += CT_THREADS) {
+                if (bid[k] < 0) continue;
+                const int own = jkp[bid[k]];
+                const int lin = cand[k];
+                unsigned long long t = walk_parity<true>(bm, cbm, bw, lin / bw, lin % bw, max_steps, l_y, l_x, nl);
+                t &= ~(1ull << own);
+                if (t) atomicXor(&l_par[own], t);
+            }
+            __syncthreads();
+            if (tid < nl) {
+                bool inside = false;
+                for (int x = 0; x < nl; ++x) inside |= (x != tid) && ((l_par[x] >> tid) & 1ull);
+                l_ext[tid] = inside ? 0 : 1;
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---- 3b. one lane per candidate walks its whole border ------------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < CPT; ++i) {
+            const int k = tid + i * CT_THREADS;
+            my_np[i] = 0;
+            if (k >= ncand) continue;
+            const int lin = cand[k];
+            const int sy = lin / bw, sx = lin - sy * bw;
+            int kept0 = 0, stored = 0, np;
+            if (k < nslots) np = moore_trace<true>(bm, bw, sy, sx, max_steps, out + (size_t)(k + 1) * slot_cap * 2, slot_cap, bx0, by0, &kept0, &stored);
+            else np = moore_trace<false>(bm, bw, sy, sx, max_steps, nullptr, 0, bx0, by0, &kept0, &stored);
+            if (k < nslots) s_stored[k] = stored;
+            if (np > 0) {
+                my_np[i] = (np << 1) | kept0;
+                const int li = atomicAdd(&s_nl, 1);
+                if (li < CT_NLMAX) { l_k[li] = k; l_np[li] = np; l_sk[li] = kept0; l_y[li] = sy; l_x[li] = sx; l_ext[li] = 1; }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int ns = s_nl;
+        if (ns >= 2 && p.strategy == 1) {
+            if (ns > CT_NLMAX) { decline(-2); return; }
+#pragma unroll
+            for (int i = 0; i < CPT; ++i) {
+                const int k = tid + i * CT_THREADS;
+                if (my_np[i] == 0) continue;
+                int own = 0;
+                while (l_k[own] != k) ++own;
+                const int lin = cand[k];
+                unsigned long long t = walk_parity<false>(bm, nullptr, bw, lin / bw, lin % bw, max_steps, l_y, l_x, ns);
+                t &= ~(1ull << own);
+                if (t) atomicXor(&l_par[own], t);
+            }
+            __syncthreads();
+            if (tid < ns) {
+                bool inside = false;
+                for (int x = 0; x < ns; ++x) inside |= (x != tid) && ((l_par[x] >> tid) & 1ull);
+                l_ext[tid] = inside ? 0 : 1;
+            }
+            __syncthreads();
+        } else if (ns >= 2) {
+            // "largest" among possibly thousands of borders (noise masks): take the best, test IT against the borders that start before it
+            // (only those can surround it), drop it if it is nested, again - a handful of rounds at most
+            bool found = false;
+            for (int round = 0; round < 16 && !found; ++round) {
+                if (tid == 0) { s_key = 0ull; s_in = 0; }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < CPT; ++i)                      // most points, then the later start (first in the bottom-up list)
+                    if (my_np[i]) atomicMax(&s_key, ((unsigned long long)(unsigned)(my_np[i] >> 1) << 40) | ((unsigned long long)(unsigned)cand[tid + i * CT_THREADS] << 16) | (unsigned long long)(tid + i * CT_THREADS));
+                __syncthreads();
+                const unsigned long long key = s_key;
+                const int kw = (int)(key & 0xffffull), lw = (int)((key >> 16) & 0xffffffull);
+                if (tid == 0) { s_qw[0] = lw / bw; s_qw[1] = lw % bw; }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < CPT; ++i) {
+                    const int k = tid + i * CT_THREADS;
+                    if (my_np[i] == 0 || cand[k] >= lw) continue;
+                    const int lin = cand[k];
+                    if (walk_parity<false>(bm, nullptr, bw, lin / bw, lin % bw, max_steps, &s_qw[0], &s_qw[1], 1) & 1ull) s_in = 1;
+                }
+                __syncthreads();
+                if (s_in == 0) {
+                    found = true;
+                    if (tid == 0) { l_k[0] = kw; l_np[0] = (int)(key >> 40); l_y[0] = s_qw[0]; l_x[0] = s_qw[1]; l_ext[0] = 1; s_nl = 1; }
+#pragma unroll
+                    for (int i = 0; i < CPT; ++i)
+                        if (tid + i * CT_THREADS == kw) l_sk[0] = my_np[i] & 1;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < CPT; ++i)
+                        if (tid + i * CT_THREADS == kw) my_np[i] = 0;
+                }
+                __syncthreads();
+            }
+            if (!found) { decline(-2); return; }
+        }
+    }
+    CT_STAMP(4);
+    // ---- 4. order, assemble, turn round ------------------------------------------------------------------------------------------------
+    const int nl = min(s_nl, CT_NLMAX);
+    if (tid == 0) {
+        int no = 0, total = 0;
+        if (p.strategy == 1) {                                     // every external contour, bottom-up
+            for (int i = 0; i < nl; ++i) if (l_ext[i]) l_ord[no++] = i;
+            for (int a = 1; a < no; ++a) {
+                const int v = l_ord[a];
+                const int key = l_y[v] * bw + l_x[v];
+                int b = a - 1;
+                while (b >= 0 && l_y[l_ord[b]] * bw + l_x[l_ord[b]] < key) { l_ord[b + 1] = l_ord[b]; --b; }
+                l_ord[b + 1] = v;
+            }
+        } else {                                                   // most points; on a tie the first of the bottom-up list = the later start
+            int best = -1;
+            for (int i = 0; i < nl; ++i) {
+                if (!l_ext[i]) continue;
+                if (best < 0 || l_np[i] > l_np[best] || (l_np[i] == l_np[best] && l_y[i] * bw + l_x[i] > l_y[best] * bw + l_x[best])) best = i;
+            }
+            if (best >= 0) l_ord[no++] = best;
+        }
+        for (int a = 0; a < no; ++a) { l_base[a] = total; total += l_np[l_ord[a]]; }
+        s_no = no; s_total = total;
+    }
+    __syncthreads();
+    const int no = s_no, total = s_total;
+    if (no == 0 || total > p.max_pts) { decline(no == 0 ? 0 : -2); return; }
+    // the head region (slot_cap points) holds the whole list when every contour is to be copied out of the candidates' slots; a longer
+    // list is re-traced contour by contour by one lane straight into place (it may then run over the slots: nothing reads them any more)
+    const bool copy_ok = total <= slot_cap;
+    for (int a = 0; a < no; ++a) {
+        const int li = l_ord[a], kb = l_k[li], npq = l_np[li], rotq = l_sk[li], base = l_base[a];
+        const int sy = l_y[li], sx = l_x[li];
+        __shared__ int s_cyc_len, s_par_ok;
+        if (tid == 0) {
+            bool ok = copy_ok;
+            int len = 0;
+            if (ok && seg_mode) {
+                // the contour's segments in order with the output offset of their points
+                int off = base + rotq, j = kb, moves = 0;
+                while (ok) {
+                    if (j >= nslots || nkp[j] > slot_cap) { ok = false; break; }
+                    const int jn = nxt[j];
+                    int joint = 0;
+                    if (j != kb) {                                 // the joint point at this segment's start
+                        const int q = cyc[len - 1];
+                        joint = (((mvs[q] >> 4) & 15) != (mvs[j] & 15)) ? 1 : 0;
+                    }
+                    jkp[j] = joint;
+                    off += joint;
+                    moves += nmv[j];
+                    cyc[len++] = j;
+                    const int myoff = off;
+                    off += nkp[j];
+                    nmv[j] = myoff;                                // (moves are no longer needed: the slot becomes the offset)
+                    j = jn;
+                    if (j == kb) break;
+                    if (len >= ncand) { ok = false; break; }
+                }
+                if (ok && (moves <= 2 || off != base + npq)) ok = false;      // tiny borders and any disagreement go the serial way
+            } else if (ok) {
+                ok = kb < nslots && s_stored[kb] == npq - rotq && npq - rotq <= slot_cap;
+            }
+            s_par_ok = ok ? 1 : 0;
             s_cyc_len = len;
         }
         __syncthreads();
-        const int sy = linq / bw, sx = linq - sy * bw;
-        if (s_seg_ok) {
+        if (s_par_ok && seg_mode) {
             const int len = s_cyc_len;
             for (int i = wave; i < len; i += CT_THREADS / 64) {     // a wave per segment: joint point, then the segment's list
                 const int j = cyc[i];
@@ -429,64 +665,42 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
                 const int32_t* sp = out + (size_t)(j + 1) * slot_cap * 2;
                 for (int q = lane; q < 2 * nkp[j]; q += 64) out[2 * o0 + q] = sp[q];
             }
-            if (tid == 0 && rotq) { out[0] = sx + bx0; out[1] = sy + by0; }
+            if (tid == 0 && rotq) { out[2 * base] = sx + bx0; out[2 * base + 1] = sy + by0; }
+        } else if (s_par_ok) {
+            const int32_t* sp = out + (size_t)(kb + 1) * slot_cap * 2;
+            for (int j = tid; j < 2 * (npq - rotq); j += CT_THREADS) out[2 * (base + rotq) + j] = sp[j];
+            if (tid == 0 && rotq) { out[2 * base] = sx + bx0; out[2 * base + 1] = sy + by0; }
         } else if (tid == 0) {
             int kept0 = 0, stored = 0;
-            moore_trace<true>(bm, bw, sy, sx, max_steps, out + 2 * rotq, p.max_pts - rotq, bx0, by0, &kept0, &stored);
-            if (rotq) { out[0] = sx + bx0; out[1] = sy + by0; }
-        }
-        if (tid == 0) {
-            p.count[mi] = npq;
-            s_np = npq;
-            if (blockIdx.x == 0) g_ct_clk[9] = (unsigned long long)npq;
+            moore_trace<true>(bm, bw, sy, sx, max_steps, out + 2 * (base + rotq), p.max_pts - base - rotq, bx0, by0, &kept0, &stored);
+            if (rotq) { out[2 * base] = sx + bx0; out[2 * base + 1] = sy + by0; }
         }
         __threadfence_block();
-        seg_done = true;
+        __syncthreads();
     }
-    int my_np = 0, my_stored = 0, my_k = -1;                        // (a thread traces at most one candidate with a slot: slots < CT_THREADS)
-    for (int k = tid; !seg_done && k < ncand; k += CT_THREADS) {
-        const int lin = cand[k];
-        const int sy = lin / bw, sx = lin - sy * bw;
-        int kept0 = 0, stored = 0, np;
-        if (k < nslots) np = moore_trace<true>(bm, bw, sy, sx, max_steps, out + (size_t)(k + 1) * slot_cap * 2, slot_cap, bx0, by0, &kept0, &stored);
-        else np = moore_trace<false>(bm, bw, sy, sx, max_steps, nullptr, 0, bx0, by0, &kept0, &stored);
-        // most points wins, ties go to the first start in raster order; the low bit carries "the start point leads the list"
-        if (np > 0) atomicMax(&s_best, ((unsigned long long)(unsigned)np << 32) | ((unsigned long long)(0x7fffffffu - (unsigned)lin) << 1) | (unsigned)kept0);
-        if (k < nslots) { my_np = np; my_stored = stored; my_k = k; }
+    // the walkers go clockwise (east first); cv2 follows an outer border the other way (down first) from the same start pixel: the kept
+    // pixels are the same set, so each contour's list is turned round behind its start point
+    for (int a = 0; a < no; ++a) {
+        const int li = l_ord[a];
+        const int lo = l_base[a] + l_sk[li], hi = l_base[a] + l_np[li] - 1;        // reverse out[lo .. hi]
+        for (int i = tid; lo + i < hi - i; i += CT_THREADS) {
+            const int u = lo + i, v = hi - i;
+            const int ux = out[2 * u], uy = out[2 * u + 1];
+            out[2 * u] = out[2 * v]; out[2 * u + 1] = out[2 * v + 1];
+            out[2 * v] = ux; out[2 * v + 1] = uy;
+        }
+    }
+    if (tid == 0) {
+        p.count[mi] = total;
+        s_np = total;
+        if (p.parts) {
+            int32_t* pp = p.parts + (size_t)mi * p.parts_cap;
+            pp[0] = no;
+            for (int a = 0; a < no && a + 1 < p.parts_cap; ++a) pp[a + 1] = l_np[l_ord[a]];
+        }
+        if (blockIdx.x == 0) g_ct_clk[9] = (unsigned long long)total;
     }
     __threadfence_block();
-    __syncthreads();
-    if (!seg_done) CT_STAMP(4);
-    // ---- 4. the winner's points, hull, rectangle ------------------------------------------------------------------------------
-    const unsigned long long best = s_best;
-    const int np_best = (int)(best >> 32);
-    if (!seg_done && (np_best > p.max_pts || np_best <= 0)) {
-        if (tid == 0) { p.count[mi] = np_best > 0 ? -2 : 0; if (p.rect) { p.rect[2 * mi] = 0.0; p.rect[2 * mi + 1] = 0.0; } }
-        return;
-    }
-    if (!seg_done) {
-        const int lin = (int)(0x7fffffffu - (unsigned)((best & 0xffffffffull) >> 1));
-        const int rot = (int)(best & 1ull);                      // 1: the start point is point 0 of the list
-        const int sy = lin / bw, sx = lin - sy * bw;
-        if (my_k >= 0 && cand[my_k] == lin && my_np == np_best && my_stored <= slot_cap && np_best <= slot_cap) { s_win_slot = my_k; s_win_stored = my_stored; }
-        __syncthreads();
-        const int slot = s_win_slot;
-        if (slot >= 0) {                                         // every thread copies: the list is rot + stored points long
-            const int32_t* sp = out + (size_t)(slot + 1) * slot_cap * 2;
-            for (int j = tid; j < 2 * s_win_stored; j += CT_THREADS) out[2 * rot + j] = sp[j];
-            if (tid == 0 && rot) { out[0] = sx + bx0; out[1] = sy + by0; }
-        } else if (tid == 0) {                                   // no slot, or a list longer than one: trace once more, straight into the head
-            int kept0 = 0, stored = 0;
-            moore_trace<true>(bm, bw, sy, sx, max_steps, out + 2 * rot, p.max_pts - rot, bx0, by0, &kept0, &stored);
-            if (rot) { out[0] = sx + bx0; out[1] = sy + by0; }
-        }
-        if (tid == 0) {
-            p.count[mi] = np_best;
-            s_np = np_best;
-            if (blockIdx.x == 0) g_ct_clk[9] = (unsigned long long)np_best;
-        }
-        __threadfence_block();
-    }
     __syncthreads();                          // (the bit image is dead from here on: its LDS becomes the hull's tables)
     CT_STAMP(5);
     if (!p.rect) return;
@@ -621,9 +835,10 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
 
 hipError_t contour_read_clocks(unsigned long long* out12) { return hipMemcpyFromSymbol(out12, HIP_SYMBOL(g_ct_clk), 12 * sizeof(unsigned long long)); }
 
-hipError_t launch_contours(const uint8_t* masks, int n, int H, int W, int max_pts, int32_t* pts, int32_t* count, double* rect, hipStream_t st) {
+hipError_t launch_contours(const uint8_t* masks, int n, int H, int W, int strategy, int max_pts, int32_t* pts, int32_t* count, int32_t* parts, int parts_cap,
+                           double* rect, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    ContourParams p{masks, n, H, W, max_pts, pts, count, rect, 0};
+    ContourParams p{masks, n, H, W, max_pts, pts, count, strategy, parts, parts ? parts_cap : 0, rect, 0};
     p.boxg = max_pts / 2 < CT_BOXG ? max_pts / 2 : CT_BOXG;      // a partial box takes two points' worth of the list
     if (p.boxg < 1) return hipErrorInvalidValue;
     const size_t sh = (size_t)CT_BITMAP_BYTES + (size_t)CT_MAXCAND * sizeof(int);

@@ -32,9 +32,14 @@ template <> struct TT<float> {
     struct __attribute__((aligned(16))) Frag { float v[8]; };
     // lane-group g=(lane>>4) owns k = 8g..8g+7; MFMA j sums element j of all four groups: any k bijection is
     // valid as long as A and B use the same one.
+    // Blocked summation: the 32 products of a k-tile are summed on their own and the block sum is added to the running total, as a
+    // vectorised CPU kernel (the reference's oneDNN path) keeps partial sums per lane - one K-long sequential fp32 chain carried about
+    // twice that path's rounding noise through the network (measured against the fp64 oracle).
     __device__ static inline void mma(f32x4& acc, const Frag& a, const Frag& b) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], acc, 0, 0, 0);
+        for (int j = 0; j < 8; ++j) t = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], t, 0, 0, 0);
+        acc += t;
     }
 };
 
@@ -43,7 +48,9 @@ template <> struct TT<float> {
 // derivation in DESIGN.md "conv_igemm LDS image".
 __device__ __forceinline__ int swz(int row, int c) { return c ^ ((4 - ((row >> 2) & 3)) & 3); }
 
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+// (fp32 parity mode and the register-staged bf16 fallback: the library expf and an IEEE division - the LDS-DMA kernels of the bf16 hot path
+// have their own packed form, common.h silu4_packed)
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 template <typename T, int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {

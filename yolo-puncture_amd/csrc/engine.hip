@@ -785,10 +785,13 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
 
 static int allocate_plan(yp_engine& e) {
     if (e.allocated) return YP_OK;
-    // A dense conv packed with padded taps (WeightDesc::cin_pad > Cin, see conv_params) reads cin_pad channels per pixel: at the last
-    // pixel of the last image that is up to (cin_pad - Cin) * 2 < 64 bytes past the end of its input tensor, multiplied by zero weights.
-    // Those bytes must be finite bf16 patterns (NaN * 0 = NaN on the matrix cores), so every such tensor owns a 64-byte tail behind its
-    // payload that is part of its slot and is zeroed on EVERY layout (a re-plan into the kept arena leaves stale fp32 / u32 bytes there).
+    // A dense conv packed with padded taps (WeightDesc::cin_pad > Cin, see conv_params) reads cin_pad channels per pixel and multiplies the
+    // surplus by zero weights: the surplus bytes are the next channels of the same pixel (in a concat buffer: a slice a LATER op writes), the
+    // next pixel, or - at the last pixel of the last image - up to (cin_pad - Cin) * 2 < 64 bytes past the end of the tensor. Every one of
+    // those bytes must be a finite bf16 pattern (NaN * 0 = NaN on the matrix cores; a NaN output then lands in the very slice the next
+    // forward over-reads, i.e. it would never heal). So (i) a tensor read by such a conv owns a 64-byte tail inside its slot, and (ii) the
+    // whole region of a layout is zeroed on EVERY layout, not only when the arena grows: a re-plan into the kept arena puts bf16 tensors
+    // over stale fp32 logits / u32 keys, whose low halves read as bf16 NaN once in 256.
     std::vector<char> tail(e.tensors.size(), 0);
     for (const auto& o : e.ops)
         if (o.kind == OP_CONV && o.widx >= 0 && o.in.t >= 0 && e.weights[o.widx].cin_pad > o.in.C) tail[o.in.t] = 1;
@@ -801,14 +804,12 @@ static int allocate_plan(yp_engine& e) {
         if (e.arena) HIPCHK(hipFree(e.arena));
         e.arena = nullptr;
         HIPCHK(hipMalloc(&e.arena, total));
-        HIPCHK(hipMemset(e.arena, 0, total));
         e.arena_bytes = total;
     }
+    HIPCHK(hipMemset(e.arena, 0, total));            // (2.9 GB at S / bs 32: ~1 ms, once per plan)
     size_t off = 0;
     for (size_t i = 0; i < e.tensors.size(); ++i) {
-        TensorDesc& t = e.tensors[i];
-        t.ptr = (char*)e.arena + off;
-        if (tail[i]) HIPCHK(hipMemset((char*)t.ptr + t.bytes, 0, slot(i) - t.bytes));
+        e.tensors[i].ptr = (char*)e.arena + off;
         off += slot(i);
     }
     {
@@ -1854,11 +1855,14 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     return YP_OK;
 }
 
-int yp_mask_contours(const uint8_t* masks_dev, int n, int H, int W, int max_pts, int32_t* pts_out, int32_t* count_out, double* rect_out, void* stream) {
+int yp_mask_contours(const uint8_t* masks_dev, int n, int H, int W, int strategy, int max_pts, int32_t* pts_out, int32_t* count_out, int32_t* parts_out,
+                     int parts_cap, double* rect_out, void* stream) {
     if (n < 0 || H <= 0 || W <= 0 || max_pts < 2) return fail(YP_ERR_ARG, "yp_mask_contours: bad sizes (max_pts >= 2)");
+    if (strategy != YP_CONTOURS_LARGEST && strategy != YP_CONTOURS_ALL) return fail(YP_ERR_ARG, "yp_mask_contours: strategy must be YP_CONTOURS_LARGEST or YP_CONTOURS_ALL");
     if (n > 0 && (!masks_dev || !pts_out || !count_out)) return fail(YP_ERR_ARG, "yp_mask_contours: null buffer");
+    if (parts_out && parts_cap < 2) return fail(YP_ERR_ARG, "yp_mask_contours: parts_cap >= 2 with a parts buffer");
     if ((long)H * W >= (1l << 31)) return fail(YP_ERR_ARG, "yp_mask_contours: image too large");
-    HIPCHK(launch_contours(masks_dev, n, H, W, max_pts, pts_out, count_out, rect_out, (hipStream_t)stream));
+    HIPCHK(launch_contours(masks_dev, n, H, W, strategy, max_pts, pts_out, count_out, parts_out, parts_cap, rect_out, (hipStream_t)stream));
     return YP_OK;
 }
 

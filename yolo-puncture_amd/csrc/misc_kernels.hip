@@ -6,7 +6,7 @@
 
 namespace yp {
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }   // fp32 parity mode: library expf, IEEE division
 // bf16 storage: v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~12 instructions) - same form as the conv epilogues
 __device__ __forceinline__ float silu_q(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 template <typename T> __device__ __forceinline__ float silu_t(float x) { return sizeof(T) == 2 ? silu_q(x) : silu_f(x); }

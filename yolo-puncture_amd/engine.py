@@ -127,36 +127,45 @@ def letterbox_device(src: torch.Tensor, geo: dict, out: Optional[torch.Tensor] =
     return out
 
 
-def mask_contours_device(masks: torch.Tensor, max_pts: Optional[int] = None, want_rect: bool = True):
+CONTOUR_STRATEGIES = {"largest": 0, "all": 1}      # include/yolop.h YP_CONTOURS_*
+_PARTS_CAP = 65                                     # [count | up to 64 contour lengths] (csrc/contour.hip CT_NLMAX)
+
+
+def mask_contours_device(masks: torch.Tensor, max_pts: Optional[int] = None, want_rect: bool = True, strategy: str = "all", want_parts: bool = False):
     """yp_mask_contours: uint8 cuda [n,H,W] -> (list of int32 [m,2] numpy polygons (None where the device path declined), rect float64 [n,2]
-    numpy (long side, short side) or None). The masks stay on the device; counts, rectangles and the heads of the point lists share one
-    allocation so that a single mask (what the reference's loop asks for per frame) costs ONE device-to-host copy. `max_pts` also sizes
-    the kernel's per-candidate lists (1024 points each behind the result): the default is generous for one mask, 16384 per mask otherwise."""
+    numpy (long side, short side) or None[, list of per-mask contour lengths when `want_parts`]). `strategy` as ultralytics' masks2segments:
+    "all" (every external contour, concatenated bottom-up) or "largest". The masks stay on the device; counts, contour lengths, rectangles
+    and the heads of the point lists share one allocation so that a single mask (what the reference's loop asks for per frame) costs ONE
+    device-to-host copy. `max_pts` also sizes the kernel's per-candidate lists (1024 points each behind the result): the default is
+    generous for one mask, 16384 per mask otherwise."""
     if not (masks.is_cuda and masks.dtype == torch.uint8 and masks.dim() == 3):
         raise ValueError("mask_contours_device needs a uint8 CUDA tensor [n,H,W]")
+    if strategy not in CONTOUR_STRATEGIES:
+        raise ValueError(f"strategy must be 'all' or 'largest', got {strategy!r}")
     masks = masks.contiguous()
     n, H, W = (int(v) for v in masks.shape)
     if max_pts is None:
         max_pts = 131072 if n <= 2 else 16384
     dev = masks.device
-    # int32 words: [count (n) | pad | rect (n x 2 float64) | points (n x max_pts x 2)]
-    o_rect = (n + 1) // 2 * 2
+    # int32 words: [count (n) | pad | parts (n x _PARTS_CAP, padded to even) | rect (n x 2 float64) | points (n x max_pts x 2)]
+    o_parts = (n + 1) // 2 * 2
+    o_rect = o_parts + (n * _PARTS_CAP + 1) // 2 * 2
     o_pts = o_rect + 4 * n
     buf = torch.empty((o_pts + n * max_pts * 2,), dtype=torch.int32, device=dev)
     lib = load_library()
     with torch.cuda.device(dev):
         base = buf.data_ptr()
-        rc = lib.yp_mask_contours(C.c_void_p(masks.data_ptr()), n, H, W, int(max_pts), C.c_void_p(base + 4 * o_pts), C.c_void_p(base),
-                                  C.c_void_p(base + 4 * o_rect if want_rect else None), C.c_void_p(_stream_ptr(dev)))
+        rc = lib.yp_mask_contours(C.c_void_p(masks.data_ptr()), n, H, W, CONTOUR_STRATEGIES[strategy], int(max_pts), C.c_void_p(base + 4 * o_pts),
+                                  C.c_void_p(base), C.c_void_p(base + 4 * o_parts), _PARTS_CAP, C.c_void_p(base + 4 * o_rect if want_rect else None),
+                                  C.c_void_p(_stream_ptr(dev)))
     if rc != 0:
         raise YolopError(lib.yp_last_error().decode())
     if n == 0:
-        return [], (np.zeros((0, 2)) if want_rect else None)
+        return ([], (np.zeros((0, 2)) if want_rect else None), []) if want_parts else ([], (np.zeros((0, 2)) if want_rect else None))
     head_pts = min(max_pts, 1024)
     if n == 1:
         h = buf[:o_pts + 2 * head_pts].cpu().numpy()
         c = h[:1]
-        rect = h[o_rect:o_rect + 4].view(np.float64).reshape(1, 2).copy() if want_rect else None
         if c[0] > head_pts:
             host = buf[o_pts:o_pts + 2 * int(c[0])].cpu().numpy().reshape(1, -1, 2)
         else:
@@ -164,11 +173,15 @@ def mask_contours_device(masks: torch.Tensor, max_pts: Optional[int] = None, wan
     else:
         h = buf[:o_pts].cpu().numpy()
         c = h[:n]
-        rect = h[o_rect:o_rect + 4 * n].view(np.float64).reshape(n, 2).copy() if want_rect else None
         top = int(max(1, c.max()))
         host = buf[o_pts:].view(n, max_pts, 2)[:, :top].cpu().numpy()
+    rect = h[o_rect:o_rect + 4 * n].view(np.float64).reshape(n, 2).copy() if want_rect else None
     polys = [host[i, :c[i]].copy() if c[i] >= 0 else None for i in range(n)]
-    return polys, rect
+    if not want_parts:
+        return polys, rect
+    pr = h[o_parts:o_parts + n * _PARTS_CAP].reshape(n, _PARTS_CAP)
+    parts = [[int(v) for v in pr[i, 1:1 + min(int(pr[i, 0]), _PARTS_CAP - 1)]] if c[i] >= 0 else None for i in range(n)]
+    return polys, rect, parts
 
 
 class Engine:

@@ -123,13 +123,24 @@ def scale_coords(img1_hw: Sequence[int], coords: np.ndarray, img0_hw: Sequence[i
     return c
 
 
-# ---- Masks.xy (A.7): external contour of the largest blob, straight runs compressed ----------------------------------
+# ---- Masks.xy (A.7): cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + masks2segments, restated ----------------------------
+# Definitions this module and the device kernel (csrc/contour.hip) both implement - cv2 is absent here, so they are stated, not pinned:
+#   * foreground 8-connected, background 4-connected (the pairing of Suzuki & Abe's border following, which cv2.findContours implements);
+#   * an OUTER border belongs to one 8-connected blob; it is EXTERNAL (what RETR_EXTERNAL keeps) iff the blob is not enclosed by another
+#     blob, i.e. iff the background pixel west of the blob's raster-first pixel is 4-connected to the image frame. A blob inside a hole of
+#     another blob is NOT external and is skipped, as cv2 skips it;
+#   * a contour starts at its blob's raster-first pixel and runs DOWN first (counter-clockwise on screen: for a filled rectangle top-left,
+#     bottom-left, bottom-right, top-right - the order cv2 returns); CHAIN_APPROX_SIMPLE keeps a pixel iff the move into it differs from
+#     the move out of it (the start pixel included, judged on the closed chain);
+#   * contours are listed bottom-up: descending raster order of their start pixels (cv2 returns the last contour it found first);
+#   * masks2segments [U]: strategy "largest" = the contour with the most points (first in list order on a tie), "all" (the default of the
+#     8.3.x line that YOLO11 weights need) = all contours concatenated in list order.
 _DIRS = [(0, 1), (1, 1), (1, 0), (1, -1), (0, -1), (-1, -1), (-1, 0), (-1, 1)]   # (dy,dx), clockwise from east
 
 
 def _trace_outer(mask: np.ndarray, sy: int, sx: int) -> List[Tuple[int, int]]:
     """Moore-neighbour boundary trace (8-connectivity) of the blob containing (sy,sx), which must be its first pixel
-    in raster order; Jacob's stopping criterion."""
+    in raster order; Jacob's stopping criterion. Clockwise on screen (east first); `_cv_order` turns the chain round."""
     H, W = mask.shape
 
     def on(y, x):
@@ -159,7 +170,7 @@ def _trace_outer(mask: np.ndarray, sy: int, sx: int) -> List[Tuple[int, int]]:
 
 
 def _compress(pts: List[Tuple[int, int]]) -> np.ndarray:
-    """CHAIN_APPROX_SIMPLE: keep only the end points of horizontal / vertical / diagonal runs."""
+    """CHAIN_APPROX_SIMPLE on a closed chain in the order given: keep only the end points of horizontal / vertical / diagonal runs."""
     n = len(pts)
     if n <= 2:
         return np.asarray(pts, dtype=np.int32).reshape(-1, 2)
@@ -175,27 +186,52 @@ def _compress(pts: List[Tuple[int, int]]) -> np.ndarray:
     return np.asarray(keep, dtype=np.int32)
 
 
-def largest_external_contour(mask: np.ndarray) -> np.ndarray:
-    """[m,2] (x,y) int32 polygon: the external contour with the most points (ultralytics masks2segments 'largest')."""
+def _cv_order(pts: List[Tuple[int, int]]) -> np.ndarray:
+    """The clockwise chain of `_trace_outer` walked the other way round from the same start pixel (the direction cv2 follows an outer
+    border in), then CHAIN_APPROX_SIMPLE. The kept pixels are the same set - a pixel is a run end in either direction."""
+    if len(pts) <= 2:
+        return _compress(pts)
+    return _compress([pts[0]] + pts[:0:-1])
+
+
+def external_contours(mask: np.ndarray) -> List[np.ndarray]:
+    """cv2.findContours(mask, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)[0] as defined at the top of this section: list of int32 [m,2] (x,y)."""
     from scipy import ndimage
     mask = np.asarray(mask, dtype=bool)
     lab, n = ndimage.label(mask, structure=np.ones((3, 3), dtype=int))
-    best = np.zeros((0, 2), dtype=np.int32)
     if n == 0:
-        return best
-    first = ndimage.find_objects(lab)
-    for k in range(1, n + 1):
-        sl = first[k - 1]
+        return []
+    holes = ndimage.binary_fill_holes(mask) & ~mask          # (default structure: the background is invaded 4-connectedly from the frame)
+    found = []
+    for k, sl in enumerate(ndimage.find_objects(lab), start=1):
         sub = lab[sl] == k
         ys, xs = np.nonzero(sub)
         sy = ys.min()
         sx = xs[ys == sy].min()
-        pts = _trace_outer(sub, int(sy), int(sx))
-        poly = _compress(pts)
-        poly = poly + np.asarray([sl[1].start, sl[0].start], dtype=np.int32)
-        if poly.shape[0] > best.shape[0]:
-            best = poly
-    return best
+        gy, gx = int(sy) + sl[0].start, int(sx) + sl[1].start
+        if gx > 0 and holes[gy, gx - 1]:
+            continue                                         # the blob sits in a hole of another blob: not an external contour
+        poly = _cv_order(_trace_outer(sub, int(sy), int(sx))) + np.asarray([sl[1].start, sl[0].start], dtype=np.int32)
+        found.append((gy * mask.shape[1] + gx, poly))
+    found.sort(key=lambda t: -t[0])
+    return [p for _, p in found]
+
+
+def mask_polygon(mask: np.ndarray, strategy: str = "all") -> np.ndarray:
+    """ultralytics `masks2segments(mask, strategy)` for one mask [U]: int32 [m,2] (x,y); [0,2] for an empty mask."""
+    if strategy not in ("all", "largest"):
+        raise ValueError(f"strategy must be 'all' or 'largest', got {strategy!r}")
+    c = external_contours(mask)
+    if not c:
+        return np.zeros((0, 2), dtype=np.int32)
+    if strategy == "all":
+        return np.concatenate(c, axis=0)
+    return c[int(np.argmax([len(x) for x in c]))]
+
+
+def largest_external_contour(mask: np.ndarray) -> np.ndarray:
+    """[m,2] (x,y) int32 polygon: the external contour with the most points (ultralytics masks2segments 'largest')."""
+    return mask_polygon(mask, "largest")
 
 
 # ---- shaft length from a polygon (reference yolo_seg/utils/mask_tools.py:12-22, which calls cv2.minAreaRect) ---------------------

@@ -101,16 +101,22 @@ class Boxes:
         return x / s
 
 
+MASK_POLYGON_STRATEGY = "all"     # ultralytics masks2segments(strategy=...) [U]: "all" is the default of the 8.3.x line the app's YOLO11 weights
+                                  # need (every external contour, concatenated); "largest" that of 8.0-8.2. SURVEY A.7; set before predicting.
+
+
 class Masks:
     """.data: float {0,1} [n,H,W] (H,W = original image when retina_masks else the letterboxed input);
-    .xy: one float32 [m,2] polygon per mask (largest external contour, pixels of the original image).
+    .xy: one float32 [m,2] polygon per mask - cv2.findContours(RETR_EXTERNAL, CHAIN_APPROX_SIMPLE) + masks2segments(MASK_POLYGON_STRATEGY)
+    as hostops defines them, in pixels of the original image.
     When the masks live on the GPU the contour, its convex hull and the minimum-area rectangle are computed there
     (yp_mask_contours) and only the polygon's few hundred points travel to the host; `.min_rect` is the rectangle
     `get_coord_min_rect_len` would derive from `.xy[i]` (reference yolo_seg/app.py:101-103)."""
 
-    def __init__(self, data: Optional[torch.Tensor], orig_shape: Tuple[int, int], u8: Optional[torch.Tensor] = None):
+    def __init__(self, data: Optional[torch.Tensor], orig_shape: Tuple[int, int], u8: Optional[torch.Tensor] = None, strategy: Optional[str] = None):
         if data is None and u8 is None:
             raise ValueError("Masks needs data or u8")
+        self.strategy = strategy or MASK_POLYGON_STRATEGY
         self._data = data                 # float {0,1}; made from the uint8 masks on first use (the engine produces uint8)
         self.orig_shape = tuple(orig_shape)
         self._u8 = u8                     # the engine's uint8 masks (same pixels as data), kept for the device contour pass
@@ -128,13 +134,13 @@ class Masks:
         return tuple((self._data if self._data is not None else self._u8).shape)
 
     def cpu(self):
-        m = Masks(self.data.cpu(), self.orig_shape, self._u8)
+        m = Masks(self.data.cpu(), self.orig_shape, self._u8, self.strategy)
         m._polys, m._rects = self._polys, self._rects
         return m
 
     def numpy(self):
         d = self.data
-        m = Masks(d.detach().cpu().numpy() if isinstance(d, torch.Tensor) else d, self.orig_shape, self._u8)
+        m = Masks(d.detach().cpu().numpy() if isinstance(d, torch.Tensor) else d, self.orig_shape, self._u8, self.strategy)
         m._polys, m._rects = self._polys, self._rects
         return m
 
@@ -149,7 +155,7 @@ class Masks:
         if self._data is not None:
             d = self._data[i]
             d = d[None] if d.ndim == 2 else d
-        return Masks(d, self.orig_shape, u)
+        return Masks(d, self.orig_shape, u, self.strategy)
 
     def _contour(self, i: int) -> np.ndarray:
         """polygon of mask i (float32 [m,2], original-image pixels), computed on first use: the reference's loop touches ONE mask per
@@ -166,15 +172,15 @@ class Masks:
         u8 = self._u8
         if u8 is None and isinstance(self._data, torch.Tensor) and self._data.is_cuda:
             u8 = (self._data[i:i + 1] > 0.5).to(torch.uint8)
-            polys, rects = mask_contours_device(u8)
+            polys, rects = mask_contours_device(u8, strategy=self.strategy)
             poly, rect = polys[0], rects[0]
         elif u8 is not None and u8.is_cuda:
-            polys, rects = mask_contours_device(u8[i:i + 1])
+            polys, rects = mask_contours_device(u8[i:i + 1], strategy=self.strategy)
             poly, rect = polys[0], rects[0]
         if poly is None:                                  # (no GPU copy, or the device pass declined this mask: host trace)
             d = self.data[i]
             host = d.detach().cpu().numpy() if isinstance(d, torch.Tensor) else np.asarray(d)
-            poly = hostops.largest_external_contour(host > 0.5)
+            poly = hostops.mask_polygon(host > 0.5, self.strategy)
             rect = None
         if rect is not None and (mh, mw) == self.orig_shape:
             self._rects[i] = (float(rect[0]), float(rect[1]))   # (the device rectangle is of the polygon in mask pixels)
