@@ -35,6 +35,9 @@ extern "C" {
 #define YP_TASK_SEGMENT 1
 
 #define YP_NM 32           /* mask coefficients per detection */
+#define YP_MAX_MASKS 480   /* masks per yp_masks / yp_id_mask_resized call (one frame's coefficients stay in LDS); a YP_TASK_SEGMENT engine
+                              therefore takes max_det <= 480 - yp_create refuses more (ultralytics' default, and what every caller of the
+                              reference leaves in place, is 300: yolo_seg/app.py:91, yolo_seg/yolo_with_deva.py:51) */
 
 typedef struct yp_engine yp_engine;
 
@@ -44,7 +47,7 @@ typedef struct yp_model_desc {
     int nc;      /* number of classes                                             */
     int task;    /* YP_TASK_DETECT | YP_TASK_SEGMENT (v10 trunk + Proto/cv4 head) */
     int dtype;   /* YP_BF16 | YP_F32                                              */
-    int max_det; /* 300 (ultralytics default); top-k size of the one-to-one head  */
+    int max_det; /* 300 (ultralytics default); top-k size of the one-to-one head; <= 1024 (detect), <= YP_MAX_MASKS (segment) */
     int family;  /* YP_FAMILY_V10 (0) | YP_FAMILY_V8 | YP_FAMILY_11: which ultralytics yaml the graph follows. The v8 / 11
                     families (the checkpoints the reference's UI offers, yolo_seg/app.py:218-223) are segment models: task must
                     be YP_TASK_SEGMENT; their head ends in conf filter + NMS (yp_set_nms) instead of the v10 top-k */

@@ -50,6 +50,29 @@ def test_against_reference_fixtures(eng, tag):
     assert np.array_equal((got > 0)[~near], bits[~near]) and near.mean() < 5e-3
 
 
+def test_full_u2net_against_reference_fixture():
+    """variant 'f' of include/yolop.h = the full U^2-Net (`load_unet("u2net")`, unet_segment.py:36-37; U2Net.py:318-420): 64 ... 512
+    channels, same graph shape as U^2-Net-P. Held to a fixture the reference module produced (tests/golden/u2netf_a.npz)."""
+    z = np.load(os.path.join(GOLD, "u2netf_a.npz"))
+    B, H, W = (int(v) for v in z["shape"])
+    im = rand_image((B, H, W, 3), seed=int(z["seed"]))
+    e = U2NetEngine("f", "fp32", 0, state=synthetic_state("f", 0))
+    prob, norm, mask = e.forward(im.cuda())
+    torch.cuda.synchronize()
+    err = np.abs(prob.cpu().numpy() - z["d0"]).max()
+    print("u2net (full)", (B, H, W), "max |prob - reference| =", err)
+    assert err < 1e-3
+    s6 = e.read_tensor("stage6").permute(0, 3, 1, 2).numpy()
+    assert np.abs(s6 - z["stage6"]).max() < 1e-3 * max(1.0, np.abs(z["stage6"]).max())
+    mi, ma = float(z["norm_min"]), float(z["norm_max"])
+    want_norm = (z["d0"] - mi) / (ma - mi)
+    assert np.abs(norm.cpu().numpy() - want_norm).max() < 1e-3
+    bits = np.unpackbits(z["mask_bits"])[: B * H * W].reshape(B, H, W).astype(bool)
+    near = np.abs(want_norm - 0.5) < 1e-4
+    assert np.array_equal((mask.cpu().numpy() > 0)[~near], bits[~near]) and near.mean() < 5e-3
+    e.close()
+
+
 @pytest.mark.parametrize("shape,seed", [((1, 33, 47, 3), 5), ((3, 128, 96, 3), 6), ((1, 380, 211, 3), 7)])
 def test_against_oracle_other_shapes(eng, shape, seed):
     """odd sizes (ceil-mode pools with clipped windows, non-integer up-sampling ratios at every level), batch > 1"""

@@ -83,6 +83,7 @@ struct yp_engine {
     const uint8_t* tune_input = nullptr;  // the caller's frames of the forward that triggered the tuner (producer ops that read them)
     float nms_conf = 0.25f, nms_iou = 0.7f;
     float* d_nms = nullptr;               // device copy of [conf, iou]
+    bool nms_dirty = false;               // the host pair is newer than the device copy: the next forward rewrites it on its stream
     void* nms_ws = nullptr; size_t nms_ws_bytes = 0;
     int es() const { return dtype == DT_BF16 ? 2 : 4; }
 };
@@ -1559,6 +1560,8 @@ static void install_fatal_handlers() {
 int yp_create(const yp_model_desc* desc, int device, yp_engine** out) {
     if (!desc || !out) return fail(YP_ERR_ARG, "null argument");
     if (desc->nc <= 0 || desc->max_det <= 0 || desc->max_det > 1024) return fail(YP_ERR_ARG, "bad nc/max_det");
+    if (desc->task == YP_TASK_SEGMENT && desc->max_det > YP_MAX_MASKS)
+        return fail(YP_ERR_ARG, "segmentation engines take max_det <= %d (the mask tail keeps one frame's coefficients in LDS; ultralytics' default is 300)", YP_MAX_MASKS);
     if (desc->dtype != YP_BF16 && desc->dtype != YP_F32) return fail(YP_ERR_ARG, "bad dtype");
     if (desc->task != YP_TASK_DETECT && desc->task != YP_TASK_SEGMENT) return fail(YP_ERR_ARG, "bad task");
     install_fatal_handlers();
@@ -1685,6 +1688,7 @@ int yp_op_output(const yp_engine* e, int i, int* tensor, int* coff, int* C) {
     return YP_OK;
 }
 
+static int push_nms_params(yp_engine* e, hipStream_t st);
 int yp_op_input(const yp_engine* e, int i, int* tensor, int* coff, int* C, int* c_read) {
     if (!e || i < 0 || i >= (int)e->ops.size()) return fail(YP_ERR_ARG, "bad op index");
     const Op& o = e->ops[i];
@@ -1700,6 +1704,7 @@ int yp_run_op(yp_engine* e, int i, const uint8_t* in_dev, float* det_out, int32_
     if (!e->allocated) return fail(YP_ERR_STATE, "no forward has run yet");
     HIPCHK(hipSetDevice(e->device));
     RunArgs a{in_dev, det_out, idx_out, coeff_out};
+    if (push_nms_params(e, (hipStream_t)stream) != YP_OK) return YP_ERR_HIP;
     hipError_t err = run_op(*e, e->ops[i], a, (hipStream_t)stream);
     if (err != hipSuccess) return fail(YP_ERR_HIP, "op %s: %s", e->ops[i].name.c_str(), hipGetErrorString(err));
     return YP_OK;
@@ -1813,6 +1818,15 @@ static int prepare(yp_engine* e, int B, int H, int W, const uint8_t* in, float* 
     return YP_OK;
 }
 
+__global__ void set_pair_kernel(float* dst, float a, float b) { dst[0] = a; dst[1] = b; }
+static int push_nms_params(yp_engine* e, hipStream_t st) {
+    if (!e->nms_dirty || !e->d_nms) return YP_OK;
+    hipLaunchKernelGGL(set_pair_kernel, dim3(1), dim3(1), 0, st, e->d_nms, e->nms_conf, e->nms_iou);
+    HIPCHK(hipGetLastError());
+    e->nms_dirty = false;
+    return YP_OK;
+}
+
 int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
                float* coeff_out, void* stream) {
     int rc = prepare(e, B, H, W, in_dev, det_out);
@@ -1820,7 +1834,10 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     HIPCHK(hipSetDevice(e->device));
     hipStream_t st = (hipStream_t)stream;
     RunArgs a{in_dev, det_out, idx_out, coeff_out};
-    if (!e->use_graph) return run_all(*e, a, st);
+    if (!e->use_graph) {
+        rc = push_nms_params(e, st);
+        return rc != YP_OK ? rc : run_all(*e, a, st);
+    }
 
     // hipGraph replay on the engine's own stream, ordered against the caller's stream by events. The graph is specialised on
     // the plan and on the INPUT pointer only (frames are read in place); results land in engine-owned buffers.
@@ -1845,6 +1862,8 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     }
     HIPCHK(hipEventRecord(e->ev_in, st));
     HIPCHK(hipStreamWaitEvent(e->own_stream, e->ev_in, 0));
+    rc = push_nms_params(e, e->own_stream);
+    if (rc != YP_OK) return rc;
     HIPCHK(hipGraphLaunch(e->gexec, e->own_stream));
     {
         const size_t rows = (size_t)B * e->desc.max_det;
@@ -1958,14 +1977,12 @@ int yp_set_nms(yp_engine* e, float conf, float iou) {
     if (!e) return fail(YP_ERR_ARG, "null engine");
     if (!(conf >= 0.f && conf < 1.f) || !(iou > 0.f && iou <= 1.f)) return fail(YP_ERR_ARG, "yp_set_nms: conf in [0,1), iou in (0,1]");
     if (conf == e->nms_conf && iou == e->nms_iou) return YP_OK;
+    // The pair lives in device memory (a captured graph reads it through a pointer). It is rewritten by a one-thread kernel that the NEXT
+    // forward enqueues in front of its own launches on the stream it runs on (yp_forward: push_nms_params): stream order puts it behind
+    // every forward enqueued before and costs no synchronisation - predict(conf=0.25) and auto_segment's conf=0.9 on one engine
+    // (yolo_seg/app.py:91, yolo_seg/yolo_with_deva.py:51) used to pay a device sync + blocking copy per call.
     e->nms_conf = conf; e->nms_iou = iou;
-    if (e->d_nms) {
-        // a running forward may still read the old pair: order the update behind everything enqueued so far
-        HIPCHK(hipSetDevice(e->device));
-        HIPCHK(hipDeviceSynchronize());
-        const float v[2] = {conf, iou};
-        HIPCHK(hipMemcpy(e->d_nms, v, sizeof(v), hipMemcpyHostToDevice));
-    }
+    e->nms_dirty = true;
     return YP_OK;
 }
 
@@ -2005,10 +2022,17 @@ int yp_tuning_import(yp_engine* e, int B, int H, int W, const int32_t* cfg, int 
 
 int yp_set_graph(yp_engine* e, int enable) {
     if (!e) return fail(YP_ERR_ARG, "null engine");
-    if (e->use_graph == (enable != 0) && e->use_lanes == (enable != 2)) return YP_OK;
+    const bool lanes = enable != 2;      // 2 = graph without concurrent lanes (A/B measurements)
+    if (enable != 0 && e->use_lanes != lanes && e->gexec) {
+        // only a change of the LANE mode invalidates the captured executable; switching between eager launches and replay keeps it, so a
+        // caller that alternates one-frame calls (eager) with batches (replay) pays neither a sync nor a re-capture
+        HIPCHK(hipSetDevice(e->device));
+        HIPCHK(hipStreamSynchronize(e->own_stream));
+        (void)hipGraphExecDestroy(e->gexec);
+        e->gexec = nullptr;
+    }
     e->use_graph = enable != 0;
-    e->use_lanes = enable != 2;          // 2 = graph without concurrent lanes (A/B measurements)
-    if (e->gexec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(e->gexec); e->gexec = nullptr; }
+    if (enable != 0) e->use_lanes = lanes;
     return YP_OK;
 }
 
@@ -2063,7 +2087,7 @@ static int masks_common(yp_engine* e, int b, const float* coeff_dev, const float
     if (n > 0 && (!coeff_dev || !boxes_dev)) return fail(YP_ERR_ARG, "null coefficient / box buffer");
     if (!retina && (oh != e->pH || ow != e->pW)) return fail(YP_ERR_ARG, "retina=0 masks are produced at the letterboxed input size %dx%d", e->pH, e->pW);
     if (kept_out && !id_out) return fail(YP_ERR_ARG, "kept_out needs id_out");
-    if (n > 480) return fail(YP_ERR_ARG, "at most 480 masks per call (coefficients are LDS-resident)");
+    if (n > YP_MAX_MASKS) return fail(YP_ERR_ARG, "at most %d masks per call (coefficients are LDS-resident)", YP_MAX_MASKS);
     HIPCHK(hipSetDevice(e->device));
     const TensorDesc& t = e->tensors[e->proto_t];
     MaskParams p{};

@@ -268,7 +268,9 @@ class _ModelHandle:
 
 
 class YOLO:
-    """Drop-in for `ultralytics.YOLO` on the predict path of YOLOv10 detect / v10-seg checkpoints.
+    """Drop-in for `ultralytics.YOLO` on the predict path (reference yolo_seg/app.py:45-50,91; yolo_seg/yolo_with_deva.py:51,226) of YOLOv10
+    detect / v10-seg checkpoints and of the YOLOv8-seg / YOLO11-seg checkpoints the reference's UI offers (yolo_seg/app.py:218-223); family,
+    variant, class count and task are read from the checkpoint's state dict.
 
     model: path to an ultralytics-layout `.pt` (read without ultralytics, weights.py), or "synthetic:<n|s|m|b|l|x>[-seg]"
     (seeded weights, for tests/benchmarks: no checkpoint exists offline)."""
@@ -440,6 +442,7 @@ class YOLO:
         letterbox_device(raw, geo, out=batch[0])
         if self.family != "v10":
             eng.set_nms(conf, 0.7)
+        eng.set_graph(False)                                            # one frame per call: eager launches (see predict()); explicit, not whatever the last predict() left
         out = eng.forward(batch)
         dh = out["det"][0].cpu()                                        # (one copy; see predict())
         keep = dh[:, 4] > conf
