@@ -222,7 +222,8 @@ int yp_debug_force_conv_cfg(int cfg);
 /* Timing ablation for tools (results become wrong): 0 off, 1 conv kernels drop their stores, 2 drop their pixel loads. */
 int yp_debug_ablation(int v);
 /* Profiling hook: 100 MHz timestamps of the phases of the top-k kernel (image 0's workgroup, last launch):
-   [0] start, [1] keys loaded, [2] stage-1 select done, [3] stage-2 candidates scanned, [4] stage-2 select done, [5] decoded. */
+   [0] start, [1] keys loaded, [2] stage-1 lower bound found, [3] stage-1 select done, [4] stage-2 candidates scanned,
+   [5] stage-2 select done, [6] decoded; [7] = stage-2 rounds << 32 | candidates that entered the last round's select. */
 int yp_debug_head_clocks(uint64_t* out8);
 /* phase stamps of yp_mask_contours (mask 0): [0..6] 100-MHz ticks at box / bit image / candidates / trace / emit / hull / end, [8] candidates,
    [9] points of the winning contour, [10], [11] bounding box width, height */
@@ -233,8 +234,10 @@ int yp_debug_contour_clocks(uint64_t* out12);
 int yp_debug_host_selftest(yp_engine* e);
 
 /* hipGraph capture + replay of the forward: 0 = eager launches on the caller's stream (the library default), 1 = one hipGraph with
- * concurrent head lanes replayed on the engine's own stream (what predictor.py, bench.py and smoke() use), 2 = graph without
- * lanes (A/B). The first forward of every input shape runs once eagerly inside yp_forward before anything is captured. */
+ * concurrent head lanes replayed on the engine's own stream (what bench.py and smoke() use), 2 = graph without lanes (A/B),
+ * 3 = auto: per input shape, whichever of 0 and 1 a one-off timing inside the first yp_forward of that shape finds faster on this box
+ * (what predictor.py uses: one frame per call - yolo_seg/app.py:85-91 - runs eagerly, batches replay). The first forward of every
+ * input shape runs once eagerly inside yp_forward before anything is captured. */
 int yp_set_graph(yp_engine* e, int enable);
 
 #ifdef __cplusplus

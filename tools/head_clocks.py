@@ -14,7 +14,8 @@ torch.cuda.synchronize()
 buf = (C.c_uint64 * 8)()
 lib.yp_debug_head_clocks(buf)
 t = [int(x) for x in buf]
-names = ["load keys", "stage-1 select", "stage-2 scan", "stage-2 select", "decode"]
+names = ["load keys", "stage-1 bound T0", "stage-1 select", "stage-2 scan", "stage-2 select", "decode"]
 for i, n in enumerate(names):
     print(f"{n:16s} {(t[i + 1] - t[i]) / 100.0:8.2f} us")
-print(f"{'total':16s} {(t[5] - t[0]) / 100.0:8.2f} us")
+print(f"{'total':16s} {(t[6] - t[0]) / 100.0:8.2f} us")
+print(f"stage-2 rounds {t[7] >> 32}, candidates in the last round's select {t[7] & 0xffffffff}")

@@ -164,68 +164,62 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
     wait_vmq<0>();
     __builtin_amdgcn_s_barrier();
 
-    // Depthwise stage of one chunk ON THE MATRIX CORES: out[ch][px] = sum_taps Wdiag_tap[ch][k] * x[k][px+tap], where
-    // Wdiag_tap is the 16x32 fragment that holds w[tap][ch] on the diagonal k == ch (+16 for the upper half) and zeros
-    // elsewhere. Products with the zeros are exact zeros, accumulation is fp32: same numbers as the VALU form, but a
-    // 16 px x 32 ch x 1 tap update costs 2 MFMAs (32 cycles) instead of ~16 VALU ops per lane, and needs no bf16 unpacking.
-    // Wave w owns output rows 2w, 2w+1 of the 8-row tile; a lane of the result holds 4 consecutive channels of one pixel,
-    // which go (bias + SiLU + bf16) with one ds_write_b64 into the pixel-operand tile of the pointwise GEMM.
-    // per-lane constants of the diagonal fragments: row fr carries channel fr + 16h; lane group fc holds k = 8fc..8fc+7, so
-    // the lane has a non-zero entry only for h == fc>>1 and only when (fc&1) == fr>>3, at dword (fr&7)>>1, halfword fr&1 -
-    // the same halfword the channel occupies in its LDS dword, so a fragment register is  (LDS dword) & mask.
-    unsigned dmask[2][4];
+    // Depthwise stage of one chunk ON THE MATRIX CORES: out[ch][px] = sum_taps w[tap][ch] * x[ch][px + tap] as MFMAs whose A operand is
+    // a DIAGONAL weight fragment (exact zeros elsewhere, fp32 accumulate: same numbers as the VALU form, but no bf16 unpacking and a
+    // fraction of its issue slots). Round 3: TWO taps per MFMA. The 32-deep k of v_mfma_f32_16x16x32_bf16 is split into two halves of 16
+    // channels, k < 16 = channel k of tap A, k >= 16 = channel k - 16 of tap B: a lane of the pixel fragment (px fr, k group fc) reads its
+    // 16 bytes from the halo pixel of tap (fc >> 1) at channel piece 2h + (fc & 1), the weight fragment carries w[tap A][c] at k = c and
+    // w[tap B][c] at k = 16 + c. One MFMA then updates 16 channels x 16 pixels for two taps: 5 tap pairs x 2 channel halves = 10 MFMAs
+    // and 10 fragment builds (one LDS dword + four ANDs each) per 32-channel chunk instead of 18 + 18.
+    // A lane of the result holds 4 consecutive channels of one pixel, which go (bias + SiLU + bf16) with one ds_write_b64 into the
+    // pixel-operand tile of the pointwise GEMM. Wave w owns output row w of the 8-row tile.
+    static_assert(RPW == 1, "tap pairing is written for one depthwise row per wave");
+    // per-lane constants of the diagonal fragments: row fr carries channel fr of the half; lane group fc holds k = 8fc..8fc+7, so the lane
+    // has a non-zero entry only when (fc & 1) == fr >> 3, at dword (fr & 7) >> 1, halfword fr & 1 - the same halfword the channel occupies in
+    // its LDS dword, so a fragment register is  (LDS dword of tap (fc >> 1)) & mask.
+    unsigned dmask[4];
     {
         const bool valid = (fc & 1) == (fr >> 3);
         const unsigned hw = (fr & 1) ? 0xffff0000u : 0x0000ffffu;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dmask[h][q] = (valid && h == (fc >> 1) && q == ((fr & 7) >> 1)) ? hw : 0u;
+        for (int q = 0; q < 4; ++q) dmask[q] = (valid && q == ((fr & 7) >> 1)) ? hw : 0u;
     }
-    const int dch = (fr + 16 * (fc >> 1)) & ~1;       // even channel of the LDS dword this lane reads
+    const int tapsel = fc >> 1;                        // which tap of a pair this lane's k range belongs to
     auto dw_stage = [&](int c, int hslot, int aslot) {
         const unsigned char* hsl = Hs + hslot * HB;
         unsigned char* asl = As + aslot * BM * 64;
-        bf16x8 wd[9][2];
+        bf16x8 wd[5][2];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const unsigned wbits = *(const unsigned*)(Wdw + (c * 9 + t) * 64 + dch * 2);
+        for (int pr = 0; pr < 5; ++pr) {
+            const int t = (pr == 4) ? 8 : 2 * pr + tapsel;            // (the ninth tap has no partner: its B half gets zero weights)
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const uint4 v = make_uint4(wbits & dmask[h][0], wbits & dmask[h][1], wbits & dmask[h][2], wbits & dmask[h][3]);
-                wd[t][h] = *(const bf16x8*)&v;
+                unsigned wbits = *(const unsigned*)(Wdw + (c * 9 + t) * 64 + ((fr + 16 * h) & ~1) * 2);
+                if (pr == 4 && tapsel) wbits = 0u;
+                const uint4 v = make_uint4(wbits & dmask[0], wbits & dmask[1], wbits & dmask[2], wbits & dmask[3]);
+                wd[pr][h] = *(const bf16x8*)&v;
             }
         }
-        f32x4 dacc[RPW][2];
+        f32x4 dacc[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const f32x4 bb = lds_read16_async((const unsigned char*)(Bdw + c * 32 + 16 * h + fc * 4));
+        for (int h = 0; h < 2; ++h) dacc[h] = lds_read16_async((const unsigned char*)(Bdw + c * 32 + 16 * h + fc * 4));
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) dacc[r][h] = bb;
-        }
+        for (int pr = 0; pr < 5; ++pr) {
+            const int tA = 2 * pr, tB = (pr == 4) ? 8 : 2 * pr + 1;
+            const int hpA = (wave + tA / 3) * 18 + tA % 3, hpB = (wave + tB / 3) * 18 + tB % 3;
+            const int hp = (tapsel ? hpB : hpA) + fr;
 #pragma unroll
-        for (int hy = 0; hy < RPW + 2; ++hy)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int hp = (RPW * wave + hy) * 18 + kx + fr;
-                const bf16x8 xf = *(const bf16x8*)(hsl + swz64((unsigned)(hp * 64 + fc * 16)));
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int r = hy - ky;
-                    if (r >= 0 && r < RPW) {
-#pragma unroll
-                        for (int h = 0; h < 2; ++h)
-                            dacc[r][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[ky * 3 + kx][h], xf, dacc[r][h], 0, 0, 0);
-                    }
-                }
+            for (int h = 0; h < 2; ++h) {
+                const bf16x8 xf = *(const bf16x8*)(hsl + swz64((unsigned)(hp * 64 + (2 * h + (fc & 1)) * 16)));
+                dacc[h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[pr][h], xf, dacc[h], 0, 0, 0);
             }
-#pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int px = (RPW * wave + r) * 16 + fr;
+        }
+        {
+            const int px = wave * 16 + fr;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 __attribute__((aligned(8))) __bf16 o[4];
-                float sv[4] = {dacc[r][h][0], dacc[r][h][1], dacc[r][h][2], dacc[r][h][3]};
+                float sv[4] = {dacc[h][0], dacc[h][1], dacc[h][2], dacc[h][3]};
                 if (p.act_dw == ACT_SILU) silu4_packed(sv);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) o[i] = (__bf16)sv[i];

@@ -8,6 +8,7 @@
 #include "common.h"
 #include <algorithm>
 #include <array>
+#include <chrono>
 
 #include <cmath>
 #include <cstdarg>
@@ -57,6 +58,8 @@ struct yp_engine {
     size_t mask_ws_bytes = 0;
     // hipGraph replay
     bool use_graph = false;
+    bool graph_auto = false;              // yp_set_graph(3): replay or eager per plan, whichever a one-off timing finds faster
+    std::map<std::array<int, 3>, bool> auto_replay;
     bool fuse = true;             // dw->pw fusion (YOLOP_NO_FUSE=1 disables, for A/B)
     bool tune = true;             // plan-time autotuning of the conv tile configuration
     hipStream_t own_stream = nullptr;
@@ -1827,20 +1830,17 @@ static int push_nms_params(yp_engine* e, hipStream_t st) {
     return YP_OK;
 }
 
-int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
-               float* coeff_out, void* stream) {
-    int rc = prepare(e, B, H, W, in_dev, det_out);
-    if (rc != YP_OK) return rc;
-    HIPCHK(hipSetDevice(e->device));
-    hipStream_t st = (hipStream_t)stream;
-    RunArgs a{in_dev, det_out, idx_out, coeff_out};
-    if (!e->use_graph) {
-        rc = push_nms_params(e, st);
-        return rc != YP_OK ? rc : run_all(*e, a, st);
-    }
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-    // hipGraph replay on the engine's own stream, ordered against the caller's stream by events. The graph is specialised on
-    // the plan and on the INPUT pointer only (frames are read in place); results land in engine-owned buffers.
+static int forward_eager(yp_engine* e, const RunArgs& a, hipStream_t st) {
+    int rc = push_nms_params(e, st);
+    return rc != YP_OK ? rc : run_all(*e, a, st);
+}
+
+// hipGraph replay on the engine's own stream, ordered against the caller's stream by events. The graph is specialised on
+// the plan and on the INPUT pointer only (frames are read in place); results land in engine-owned buffers.
+static int forward_replay(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out, float* coeff_out, hipStream_t st) {
+    int rc;
     const bool seg = e->desc.task == YP_TASK_SEGMENT;
     RunArgs ag{in_dev, e->o_det, e->o_idx, seg ? e->o_coeff : nullptr};
     if (!e->gexec || e->gkey.B != B || e->gkey.H != H || e->gkey.W != W || e->gkey.in != (const void*)in_dev) {
@@ -1872,6 +1872,39 @@ int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* 
     HIPCHK(hipEventRecord(e->ev_out, e->own_stream));
     HIPCHK(hipStreamWaitEvent(st, e->ev_out, 0));
     return YP_OK;
+}
+
+int yp_forward(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out,
+               float* coeff_out, void* stream) {
+    int rc = prepare(e, B, H, W, in_dev, det_out);
+    if (rc != YP_OK) return rc;
+    HIPCHK(hipSetDevice(e->device));
+    hipStream_t st = (hipStream_t)stream;
+    RunArgs a{in_dev, det_out, idx_out, coeff_out};
+    if (!e->use_graph) return forward_eager(e, a, st);
+    if (!e->graph_auto) return forward_replay(e, in_dev, B, H, W, det_out, idx_out, coeff_out, st);
+    // auto: per plan, whichever of the two launch modes is faster ON THIS BOX for this shape. A replay pays a hop to the engine's stream,
+    // a copy-out and the graph executor's per-node cost (measured ~8 us per node against ~6 us per eager launch on ROCm 7.2): with one
+    // frame per call - the reference's call shape, yolo_seg/app.py:85-91 - its ~80 kernels are a few microseconds each and eager launches
+    // win; at 32 frames the replay wins. Timed once per plan: 6 calls of each (same inputs, same outputs), host clock around a sync.
+    auto it = e->auto_replay.find({B, H, W});
+    if (it == e->auto_replay.end()) {
+        double ms[2] = {0, 0};
+        for (int mode = 0; mode < 2; ++mode) {
+            for (int rep = 0; rep < 8; ++rep) {
+                if (rep == 2) { HIPCHK(hipStreamSynchronize(st)); ms[mode] = -now_ms(); }
+                rc = mode ? forward_replay(e, in_dev, B, H, W, det_out, idx_out, coeff_out, st) : forward_eager(e, a, st);
+                if (rc != YP_OK) return rc;
+            }
+            HIPCHK(hipStreamSynchronize(st));
+            ms[mode] += now_ms();
+        }
+        it = e->auto_replay.emplace(std::array<int, 3>{B, H, W}, ms[1] < ms[0]).first;
+        static const bool say = [] { const char* v = std::getenv("YOLOP_VERBOSE"); return v && *v == '1'; }();
+        if (say) fprintf(stderr, "[yolop] %dx%dx%d: eager %.3f ms, replay %.3f ms per call -> %s\n", B, H, W, ms[0] / 6, ms[1] / 6, it->second ? "replay" : "eager");
+        return YP_OK;                                   // (the timed calls produced this call's outputs)
+    }
+    return it->second ? forward_replay(e, in_dev, B, H, W, det_out, idx_out, coeff_out, st) : forward_eager(e, a, st);
 }
 
 int yp_mask_contours(const uint8_t* masks_dev, int n, int H, int W, int strategy, int max_pts, int32_t* pts_out, int32_t* count_out, int32_t* parts_out,
@@ -2022,6 +2055,7 @@ int yp_tuning_import(yp_engine* e, int B, int H, int W, const int32_t* cfg, int 
 
 int yp_set_graph(yp_engine* e, int enable) {
     if (!e) return fail(YP_ERR_ARG, "null engine");
+    if (enable < 0 || enable > 3) return fail(YP_ERR_ARG, "yp_set_graph: 0 eager, 1 replay with lanes, 2 replay without lanes, 3 auto");
     const bool lanes = enable != 2;      // 2 = graph without concurrent lanes (A/B measurements)
     if (enable != 0 && e->use_lanes != lanes && e->gexec) {
         // only a change of the LANE mode invalidates the captured executable; switching between eager launches and replay keeps it, so a
@@ -2030,8 +2064,10 @@ int yp_set_graph(yp_engine* e, int enable) {
         HIPCHK(hipStreamSynchronize(e->own_stream));
         (void)hipGraphExecDestroy(e->gexec);
         e->gexec = nullptr;
+        e->auto_replay.clear();
     }
     e->use_graph = enable != 0;
+    e->graph_auto = enable == 3;
     if (enable != 0) e->use_lanes = lanes;
     return YP_OK;
 }

@@ -133,14 +133,11 @@ struct SelectShared {
     unsigned count;
 };
 
-// keys[0..n) -> the k largest keys, sorted descending, in out512[0..k) (zero keys behind them). n >= k; keys are unique.
-// Radix select from the top byte down; it stops as soon as the bin that holds the k-th key is wanted whole (then the
-// threshold is the smallest key with that prefix) - in practice after the score bytes. The <= 512 survivors are ordered
-// by rank counting (two threads per key, broadcast LDS reads) instead of a barrier-bound sorting network.
+// The k-th largest of keys[0..n) (n >= k >= 1; keys unique): radix select from the top byte down; it stops as soon as the bin that holds the
+// k-th key is wanted whole (then the threshold is the smallest key with that prefix) - in practice after the score bytes.
 // `nflat`: exclusive bound of the flat indices in the keys' low words (0xFFFFFFFF - flat): the index bytes every key shares
-// (0xFF above the bound's top bit) need no counting pass.
-__device__ void select_topk_sorted(const unsigned long long* keys, int n, int k, unsigned long long* out512, unsigned long long* tmp512,
-                                   SelectShared& S, unsigned nflat) {
+// (0xFF above the bound's top bit) need no counting pass. Ends with a barrier.
+__device__ unsigned long long radix_kth(const unsigned long long* keys, int n, int k, SelectShared& S, unsigned nflat) {
     const int tid = threadIdx.x;
     if (tid == 0) { S.prefix = 0ull; S.want = (unsigned)k; S.count = 0xFFFFFFFFu; }
     __syncthreads();
@@ -198,25 +195,57 @@ __device__ void select_topk_sorted(const unsigned long long* keys, int n, int k,
         kth = S.prefix;
     }
     __syncthreads();
-    if (tid == 0) S.count = 0;
-    for (int i = tid; i < 512; i += HT) { out512[i] = 0ull; tmp512[i] = 0ull; }
-    __syncthreads();
-    for (int i = tid; i < n; i += HT) {
-        const unsigned long long key = keys[i];
-        if (key >= kth) tmp512[atomicAdd(&S.count, 1u)] = key;   // exactly k of them
+    return kth;
+}
+
+// keys[0..n) -> the k largest keys, sorted descending, in out512[0..k) (zero keys behind them). n >= k; keys are unique.
+// The <= 512 survivors of the k-th-key threshold are ordered by rank counting (two threads per key, broadcast LDS reads) instead of a
+// barrier-bound sorting network.
+__device__ void select_topk_sorted(const unsigned long long* keys, int n, int k, unsigned long long* out512, unsigned long long* tmp512,
+                                   SelectShared& S, unsigned nflat) {
+    const int tid = threadIdx.x;
+    // up to 512 keys need no threshold at all: rank every one of them and keep the ranks below k (the radix passes cost ~1.2 us each
+    // whatever n is - three barriers and a one-wave scan - and stage 2 usually arrives here with little more than k candidates)
+    int m = n;                                                  // keys that get ranked (they sit in tmp512[0..m))
+    if (n > 512) {
+        const unsigned long long kth = radix_kth(keys, n, k, S, nflat);
+        if (tid == 0) S.count = 0;
+        for (int i = tid; i < 512; i += HT) { out512[i] = 0ull; tmp512[i] = 0ull; }
+        __syncthreads();
+        for (int i = tid; i < n; i += HT) {
+            const unsigned long long key = keys[i];
+            if (key >= kth) tmp512[atomicAdd(&S.count, 1u)] = key;   // exactly k of them
+        }
+        m = k;
+    } else {
+        for (int i = tid; i < 512; i += HT) { out512[i] = 0ull; tmp512[i] = i < n ? keys[i] : 0ull; }
     }
     __syncthreads();
     {
         const int i = tid >> 1, half = tid & 1;
         const unsigned long long mykey = tmp512[i];
         unsigned rank = 0;
-        const unsigned long long* q = tmp512 + half * 256;
-#pragma unroll 8
-        for (int j = 0; j < 256; ++j) rank += (q[j] > mykey) ? 1u : 0u;
+        const int hm = (m + 1) >> 1;                            // two threads per key, half of the m keys each
+        const unsigned long long* q = tmp512 + half * hm;
+        const int nq = half ? m - hm : hm;
+        if (i < m)
+            for (int j = 0; j < nq; ++j) rank += (q[j] > mykey) ? 1u : 0u;
         rank += __shfl_xor(rank, 1, 64);
-        if (half == 0 && i < k) out512[rank] = mykey;
+        if (half == 0 && i < m && rank < (unsigned)k) out512[rank] = mykey;
     }
     __syncthreads();
+}
+
+// Append this lane's item to an LDS list with ONE atomic per wave: returns the lane's slot (valid where `have`).
+__device__ __forceinline__ unsigned wave_append(bool have, unsigned* counter) {
+    const unsigned long long m = __ballot(have);
+    if (m == 0ull) return 0u;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned)__popcll(m));
+    base = (unsigned)__shfl((int)base, leader, 64);
+    return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
 }
 
 __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, const unsigned* __restrict__ mkey) {
@@ -225,8 +254,18 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
     unsigned long long* best = lds + CAP;           // [512] sorted result of the last select
     unsigned long long* carry = best + 512;         // [512] running best-k between stage-2 rounds
     unsigned long long* tmp = carry + 512;          // [512] unsorted survivors of a select
-    int* sel = (int*)(tmp + 512);                   // [MAXK] stage-1 winners (anchor ids, rank order)
-    const float** selrow = (const float**)(sel + MAXK);   // [MAXK] their class-logit rows
+    unsigned long long* tmaxs = tmp + 512;          // [HT]  stage 1: the largest key of every thread
+    int* sel = (int*)(tmaxs + HT);                  // [MAXK] stage-1 winners (anchor ids, rank order)
+    // [MAXK] their class-logit rows, kept as GLOBAL-address-space pointers: through a generic pointer read back from LDS the gathers below
+    // become flat_load, which counts in lgkmcnt as well - every wait for the next row pointer then drains the gathers in flight
+    typedef const __attribute__((address_space(1))) float* gfptr;
+    gfptr* selrow = (gfptr*)(sel + MAXK);
+    // (kernel arguments indexed by a run-time level are re-read from the argument segment with a vector load + full wait per use)
+    const unsigned* const mk0 = p.mk[0]; const unsigned* const mk1 = p.mk[1]; const unsigned* const mk2 = p.mk[2];
+    const float* const cls0 = p.cls[0]; const float* const cls1 = p.cls[1]; const float* const cls2 = p.cls[2];
+    const float* const box0 = p.box[0]; const float* const box1 = p.box[1]; const float* const box2 = p.box[2];
+    const float* const cf0 = p.cf[0]; const float* const cf1 = p.cf[1]; const float* const cf2 = p.cf[2];
+    const int w0 = p.hw[0][1], w1 = p.hw[1][1], w2 = p.hw[2][1];
     __shared__ SelectShared S;
     __shared__ unsigned nfill;
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -234,30 +273,55 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
     const Locate locate{p.hw[0][0] * p.hw[0][1], p.hw[1][0] * p.hw[1][1], p.hw[2][0] * p.hw[2][1]};
 
     HEAD_STAMP(0);
+    if (blockIdx.x == 0 && tid == 0) g_head_clk[7] = 0ull;
     // ---- stage 1: top-k anchors by (max score desc, anchor asc) ---------------------------------------------------------
-    if (p.mk[0]) {
-        int off = 0;
-        for (int l = 0; l < 3; ++l) {                      // level by level: coalesced, no per-key level search
-            const int HWl = p.hw[l][0] * p.hw[l][1];
-            const unsigned* src = p.mk[l] + (size_t)b * HWl;
-            for (int a = tid; a < HWl; a += HT)
-                keys[off + a] = ((unsigned long long)src[a] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)(off + a));
-            off += HWl;
-        }
-    } else {
-        for (int a = tid; a < A; a += HT)
-            keys[a] = ((unsigned long long)mkey[(size_t)b * A + a] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a);
+    // Every thread keeps its <= CAP / HT keys in registers (anchor a = tid + i * HT: all loads in flight at once). The k-th largest of the
+    // HT per-thread maxima is a LOWER bound T0 of the k-th largest key (k threads hold a key >= it), so the exact select only has to
+    // look at the keys >= T0 - a few hundred instead of all 8400: one cheap select over HT keys + one over the survivors instead of
+    // four counting passes over everything (17.6 -> see DESIGN us on the tail of the graph, where this kernel runs alone).
+    constexpr int NPT = CAP / HT;
+    unsigned long long kreg[NPT];
+    unsigned long long tmx = 0ull;
+    // (unconditional loads from clamped addresses: behind a per-key `if` the compiler waits for every load before it issues the next -
+    //  nine dependent trips to memory were the 4.5 us this phase took)
+    unsigned sbits[NPT];
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int a = min(tid + i * HT, A - 1);
+        if (mk0) {                                                // (uniform)
+            int l, loc, HWl;
+            locate(a, l, loc, HWl);
+            sbits[i] = (l == 0 ? mk0 : l == 1 ? mk1 : mk2)[(size_t)b * HWl + loc];
+        } else sbits[i] = mkey[(size_t)b * A + a];
     }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int a = tid + i * HT;
+        kreg[i] = a < A ? (((unsigned long long)sbits[i] << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)a)) : 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) tmx = kreg[i] > tmx ? kreg[i] : tmx;
+    tmaxs[tid] = tmx;
+    if (tid == 0) nfill = 0u;
     __syncthreads();
     HEAD_STAMP(1);
-    select_topk_sorted(keys, A, k, best, tmp, S, (unsigned)A);
+    const unsigned long long T0 = radix_kth(tmaxs, HT, k, S, (unsigned)A);
     HEAD_STAMP(2);
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const bool have = kreg[i] != 0ull && kreg[i] >= T0;
+        const unsigned pos = wave_append(have, &nfill);
+        if (have) keys[pos] = kreg[i];
+    }
+    __syncthreads();
+    select_topk_sorted(keys, (int)nfill, k, best, tmp, S, (unsigned)A);
+    HEAD_STAMP(3);
     for (int r = tid; r < k; r += HT) {
         const int a = (int)(0xFFFFFFFFu - (unsigned)(best[r] & 0xFFFFFFFFull));
         sel[r] = a;
         int l, loc, HWl;
         locate(a, l, loc, HWl);
-        selrow[r] = p.cls[l] + ((size_t)b * HWl + loc) * p.nc;           // class-logit row of the r-th selected anchor
+        selrow[r] = (gfptr)((l == 0 ? cls0 : l == 1 ? cls1 : cls2) + ((size_t)b * HWl + loc) * p.nc);   // class-logit row of the r-th selected anchor
     }
     const unsigned thr_bits = (unsigned)(best[k - 1] >> 32);   // every selected anchor has a class with score >= this
     __syncthreads();
@@ -266,7 +330,10 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
     //      in the result (>= k candidates reach it), so only survivors enter LDS; rounds bound the LDS use exactly. ----
     // sigmoid is monotone, so a candidate can reach the stage-1 threshold only if its logit reaches logit(thr) - a margin that
     // covers the rounding of both evaluations (1e-3 in logit space moves a score by >= 2.5e-4 * s * (1 - s), far above 1 ulp
-    // unless the score saturates; above 0.999 the filter is switched off)
+    // unless the score saturates; above 0.999 the filter is switched off). The scan only COMPARES logits and appends the survivors'
+    // (logit, flat index) pairs, one LDS atomic per wave and step; their scores are evaluated afterwards on the dense list (one or two
+    // per thread) - evaluating inside the scan ran the sigmoid + atomic path of nearly every one of the 24 unrolled steps for the few
+    // lanes that needed it (15.4 us). Survivors below the exact threshold stay in the list: a superset selects the same top k.
     const float thr_f = __uint_as_float(thr_bits);
     const float lthr = (thr_f > 0.f && thr_f < 0.999f) ? (logf(thr_f / (1.0f - thr_f)) - 1e-3f) : -INFINITY;
     const int total = k * p.nc;
@@ -275,99 +342,164 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
         if (tid == 0) nfill = (unsigned)have;
         for (int i = tid; i < have; i += HT) keys[i] = carry[i];
         __syncthreads();
-        // consume candidates until the buffer could overflow: each pass takes HT*? candidates; stop when nfill + chunk > CAP
+        // consume candidates until the buffer could overflow: stop when nfill + chunk > CAP
         int f0 = done;
+        const bool vec = (p.nc & 3) == 0 && p.nc <= 256;           // whole rows as float4s (below); else candidate by candidate
         while (f0 < total) {
-            const int chunk = min(total - f0, CAP - (int)nfill);
+            const int before = (int)nfill;
+            int chunk = min(total - f0, CAP - before);
+            if (vec) chunk = (chunk / p.nc) * p.nc;                // (f0 is then always a row boundary)
             if (chunk <= 0) break;
-            const int take = min(chunk, total - f0);
-            constexpr int U = 24;                                  // independent gathers in flight per thread
-            const int qs = HT / p.nc, rs = HT - qs * p.nc;         // (r, c) of candidate f advance by (qs, rs) per HT candidates
-            for (int i0 = tid; i0 < take; i0 += U * HT) {
-                float lg[U];
-                int r = (f0 + i0) / p.nc, c = (f0 + i0) - r * p.nc;
+            const int take = chunk;
+            __syncthreads();                                         // (everyone has read nfill before anyone appends)
+            if (vec) {
+                // One CU scans k * nc candidates, so instructions per candidate are what this phase costs (80 of them per candidate in the
+                // scalar form: 11 us). Here a lane takes one float4 of a row (nc / 4 lanes per row, 64 / (nc / 4) rows per wave instruction),
+                // four compares, and the wave appends its survivors with ONE atomic per instruction.
+                const int q = p.nc >> 2, rpw = 64 / q;
+                const int lane = tid & 63, wave = tid >> 6;
+                const int lr = lane / q, lc = (lane - lr * q) * 4;
+                const int row0 = f0 / p.nc, row1 = row0 + take / p.nc;
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                typedef const __attribute__((address_space(1))) f32x4* gf4ptr;
+                constexpr int UR = 4;                              // wave instructions in flight
+                for (int rb = row0 + wave * rpw; rb < row1; rb += UR * (HT / 64) * rpw) {
+                    f32x4 v[UR];
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + u * HT;
-                    lg[u] = -INFINITY;
-                    if (i < take) lg[u] = selrow[r][c];
-                    c += rs; r += qs;
-                    if (c >= p.nc) { c -= p.nc; ++r; }
-                }
+                    for (int u = 0; u < UR; ++u) {
+                        const int r = rb + u * (HT / 64) * rpw + lr;
+                        v[u] = *(gf4ptr)(selrow[min(r, row1 - 1)] + lc);          // (unconditional: clamped row, value unused when out of range)
+                    }
 #pragma unroll
-                for (int u = 0; u < U; ++u) {
-                    const int i = i0 + u * HT;
-                    if (i < take && lg[u] >= lthr) {                  // (cheap necessary condition first: most candidates stop here)
-                        const float s = sigmoidf_(lg[u]);
-                        if (__float_as_uint(s) >= thr_bits) keys[atomicAdd(&nfill, 1u)] = make_key(s, (unsigned)(f0 + i));
+                    for (int u = 0; u < UR; ++u) {
+                        const int r = rb + u * (HT / 64) * rpw + lr;
+                        const bool on = lr < rpw && r < row1;
+                        const float e[4] = {v[u][0], v[u][1], v[u][2], v[u][3]};
+                        bool kp[4];
+                        unsigned long long m[4];
+                        unsigned cnt = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { kp[j] = on && e[j] >= lthr; m[j] = __ballot(kp[j]); cnt += (unsigned)__popcll(m[j]); }
+                        if (cnt == 0u) continue;                   // (wave-uniform)
+                        unsigned base = 0;
+                        if (lane == 0) base = atomicAdd(&nfill, cnt);
+                        base = (unsigned)__shfl((int)base, 0, 64);
+                        const unsigned long long below = (1ull << lane) - 1ull;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if (kp[j]) keys[base + (unsigned)__popcll(m[j] & below)] =
+                                ((unsigned long long)__float_as_uint(e[j]) << 32) | (unsigned long long)(unsigned)(r * p.nc + lc + j);
+                            base += (unsigned)__popcll(m[j]);
+                        }
                     }
                 }
+            } else {
+                constexpr int U = 24;                                  // independent gathers in flight per thread
+                const int qs = HT / p.nc, rs = HT - qs * p.nc;         // (r, c) of candidate f advance by (qs, rs) per HT candidates
+                for (int i0 = tid; i0 < take; i0 += U * HT) {
+                    float lg[U];
+                    int r = (f0 + i0) / p.nc, c = (f0 + i0) - r * p.nc;
+                    const int rlast = (f0 + take - 1) / p.nc;
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        // unconditional load (past the end: the last row's same column - a valid address, the value is not used): behind
+                        // `if (i < take)` the 24 gathers went to memory one after the other
+                        lg[u] = selrow[min(r, rlast)][c];
+                        c += rs; r += qs;
+                        if (c >= p.nc) { c -= p.nc; ++r; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        const int i = i0 + u * HT;
+                        const bool keep = i < take && lg[u] >= lthr;
+                        const unsigned pos = wave_append(keep, &nfill);
+                        if (keep) keys[pos] = ((unsigned long long)__float_as_uint(lg[u]) << 32) | (unsigned long long)(unsigned)(f0 + i);
+                    }
+                }
+            }
+            __syncthreads();
+            for (int j = before + tid; j < (int)nfill; j += HT) {   // the survivors' scores, on the dense list
+                const unsigned long long e = keys[j];
+                keys[j] = make_key(sigmoidf_(__uint_as_float((unsigned)(e >> 32))), (unsigned)(e & 0xFFFFFFFFull));
             }
             __syncthreads();
             f0 += take;
             if ((int)nfill + 1 >= CAP) break;
         }
         done = f0;
-        HEAD_STAMP(3);
+        HEAD_STAMP(4);
         const int n = (int)nfill;
         const int kk = min(k, n);
+        if (blockIdx.x == 0 && tid == 0) g_head_clk[7] = (g_head_clk[7] & 0xffffffff00000000ull) + (1ull << 32) + (unsigned long long)n;   // [7] = rounds << 32 | keys of the last round
         select_topk_sorted(keys, n, kk, best, tmp, S, (unsigned)(A * p.nc));
         for (int i = tid; i < kk; i += HT) carry[i] = best[i];
         have = kk;
         __syncthreads();
     }
 
-    HEAD_STAMP(4);
+    HEAD_STAMP(5);
     // ---- winners: DFL decode (softmax expectation over 16 bins per side), dist2bbox (xyxy) * stride ----------------------
-    for (int r = tid; r < p.max_det; r += HT) {
-        float* d = p.det + ((size_t)b * p.max_det + r) * 6;
-        if (r >= have) {
+    // four threads per row, one per box side (16 loads + 16 expf each instead of 64 + 64 on a quarter of the threads); lane 0 of the quad
+    // collects the distances and writes the row. Same arithmetic per side, so the same bits as one thread per row.
+    for (int r0 = 0; r0 < p.max_det; r0 += HT / 4) {
+        const int r = r0 + (tid >> 2), sd = tid & 3;
+        const bool live = r < p.max_det && r < have;
+        float dist = 0.f, score = 0.f;
+        int a = -1, cls = 0, l = 0, loc = 0, HWl = 1;
+        if (live) {
+            const unsigned long long key = carry[r];
+            score = __uint_as_float((unsigned)(key >> 32));
+            const int f = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
+            const int row = f / p.nc;
+            cls = f - row * p.nc;
+            a = sel[row];
+            locate(a, l, loc, HWl);
+            const float4* bp = (const float4*)((l == 0 ? box0 : l == 1 ? box1 : box2) + ((size_t)b * HWl + loc) * 64 + sd * 16);
+            const float4 q0 = bp[0], q1 = bp[1], q2 = bp[2], q3 = bp[3];
+            float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            float mx = -INFINITY;
 #pragma unroll
-            for (int j = 0; j < 6; ++j) d[j] = 0.f;
-            if (p.idx) p.idx[(size_t)b * p.max_det + r] = -1;
-            if (p.coeff)
-                for (int j = 0; j < 32; ++j) p.coeff[((size_t)b * p.max_det + r) * 32 + j] = 0.f;
-            continue;
-        }
-        const unsigned long long key = carry[r];
-        const float score = __uint_as_float((unsigned)(key >> 32));
-        const int f = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
-        const int row = f / p.nc, cls = f - row * p.nc;
-        const int a = sel[row];
-        int l, loc, HWl;
-        locate(a, l, loc, HWl);
-        const int Wl = p.hw[l][1];
-        const int y = loc / Wl, x = loc - y * Wl;
-        const float stride = (float)(8 << l);
-        const float* bp = p.box[l] + ((size_t)b * HWl + loc) * 64;
-        float dist[4];
-#pragma unroll
-        for (int sd = 0; sd < 4; ++sd) {
-            float v[16], mx = -INFINITY;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { v[i] = bp[sd * 16 + i]; mx = fmaxf(mx, v[i]); }
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, v[i]);
             float sum = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { v[i] = expf(v[i] - mx); sum += v[i]; }
             float e = 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) e += (v[i] / sum) * (float)i;
-            dist[sd] = e;
+            dist = e;
         }
-        const float ax = (float)x + 0.5f, ay = (float)y + 0.5f;
-        d[0] = (ax - dist[0]) * stride;
-        d[1] = (ay - dist[1]) * stride;
-        d[2] = (ax + dist[2]) * stride;
-        d[3] = (ay + dist[3]) * stride;
-        d[4] = score;
-        d[5] = (float)cls;
-        if (p.idx) p.idx[(size_t)b * p.max_det + r] = a;
+        const float d0 = __shfl(dist, (tid & 60) + 0, 64), d1 = __shfl(dist, (tid & 60) + 1, 64), d2 = __shfl(dist, (tid & 60) + 2, 64), d3 = __shfl(dist, (tid & 60) + 3, 64);
+        if (r >= p.max_det) continue;
+        float* d = p.det + ((size_t)b * p.max_det + r) * 6;
+        if (r >= have) {
+            if (sd == 0) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) d[j] = 0.f;
+                if (p.idx) p.idx[(size_t)b * p.max_det + r] = -1;
+            }
+            if (p.coeff)
+                for (int j = sd * 8; j < sd * 8 + 8; ++j) p.coeff[((size_t)b * p.max_det + r) * 32 + j] = 0.f;
+            continue;
+        }
+        if (sd == 0) {
+            const int Wl = l == 0 ? w0 : l == 1 ? w1 : w2;
+            const int y = loc / Wl, x = loc - y * Wl;
+            const float stride = (float)(8 << l);
+            const float ax = (float)x + 0.5f, ay = (float)y + 0.5f;
+            d[0] = (ax - d0) * stride;
+            d[1] = (ay - d1) * stride;
+            d[2] = (ax + d2) * stride;
+            d[3] = (ay + d3) * stride;
+            d[4] = score;
+            d[5] = (float)cls;
+            if (p.idx) p.idx[(size_t)b * p.max_det + r] = a;
+        }
         if (p.coeff) {
-            const float* cf = p.cf[l] + ((size_t)b * HWl + loc) * 32;
-            for (int j = 0; j < 32; ++j) p.coeff[((size_t)b * p.max_det + r) * 32 + j] = cf[j];
+            const float* cf = (l == 0 ? cf0 : l == 1 ? cf1 : cf2) + ((size_t)b * HWl + loc) * 32;
+            for (int j = sd * 8; j < sd * 8 + 8; ++j) p.coeff[((size_t)b * p.max_det + r) * 32 + j] = cf[j];
         }
     }
-    HEAD_STAMP(5);
+    HEAD_STAMP(6);
 }
 
 hipError_t head_read_clocks(unsigned long long* out8) { return hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_head_clk), 8 * sizeof(unsigned long long)); }
@@ -376,7 +508,7 @@ size_t head_scratch_bytes(int B, int A) { return (size_t)B * A * sizeof(unsigned
 
 hipError_t launch_head(const HeadParams& p, hipStream_t st) {
     if (p.A > CAP || p.max_det > MAXK || (p.scratch == nullptr && p.mk[0] == nullptr)) return hipErrorInvalidValue;
-    const size_t sh = (size_t)(CAP + 1536) * 8 + MAXK * 4 + MAXK * 8;
+    const size_t sh = (size_t)(CAP + 1536 + HT) * 8 + MAXK * 4 + MAXK * 8;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)head_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);

@@ -270,8 +270,11 @@ class Engine:
         """families v8 / 11: thresholds of the NMS inside the forward (`.predict(conf=, iou=)`)."""
         self._chk(self.lib.yp_set_nms(self._h, float(conf), float(iou)))
 
-    def set_graph(self, enable: bool) -> None:
-        self._chk(self.lib.yp_set_graph(self._h, 1 if enable else 0))
+    def set_graph(self, enable) -> None:
+        """False / 0: eager launches; True / 1: hipGraph replay with head lanes; 2: replay without lanes; "auto" / 3: per input shape
+        whichever of eager and replay a one-off timing finds faster (include/yolop.h yp_set_graph)."""
+        mode = 3 if enable == "auto" else int(enable)
+        self._chk(self.lib.yp_set_graph(self._h, mode))
 
     # -- hot path ------------------------------------------------------------------------------------------------
     def forward(self, im: torch.Tensor, out: Optional[dict] = None) -> dict:

@@ -381,10 +381,11 @@ class YOLO:
             # one output set per batch size (no allocation per call); everything handed to the caller below is copied out of it
             cache = self.__dict__.setdefault("_out_cache", {})
             okey = (self._dev_index, len(idxs))
-            # hipGraph replay pays from a handful of frames per call upwards; for the reference's one-frame calls (yolo_seg/app.py:85-91)
-            # eager launches pipeline better (measured, profiles/r02_latency_b1.json: 0.62 ms eager vs 0.68 ms replay per frame)
-            gmin = int(os.environ.get("YOLOP_PREDICT_GRAPH_MIN_BATCH", "8"))
-            eng.set_graph(gmin > 0 and len(idxs) >= gmin)
+            # launch mode "auto": per input shape the engine times eager launches against hipGraph replay once and keeps the faster - the
+            # reference's one-frame calls (yolo_seg/app.py:85-91) run eagerly (~80 kernels of a few microseconds: the graph executor's
+            # per-node cost loses), batches replay. YOLOP_PREDICT_GRAPH=0 / 1 forces one mode.
+            mode = os.environ.get("YOLOP_PREDICT_GRAPH", "auto")
+            eng.set_graph("auto" if mode == "auto" else int(mode))
             out = eng.forward(batch, cache.get(okey))
             cache[okey] = out
             # ONE device-to-host copy of the [B,300,6] rows ends the forward; the conf filter and scale_boxes are a few dozen floats of
@@ -442,7 +443,8 @@ class YOLO:
         letterbox_device(raw, geo, out=batch[0])
         if self.family != "v10":
             eng.set_nms(conf, 0.7)
-        eng.set_graph(False)                                            # one frame per call: eager launches (see predict()); explicit, not whatever the last predict() left
+        mode = os.environ.get("YOLOP_PREDICT_GRAPH", "auto")             # (explicit: not whatever the last predict() left; one frame resolves to eager)
+        eng.set_graph("auto" if mode == "auto" else int(mode))
         out = eng.forward(batch)
         dh = out["det"][0].cpu()                                        # (one copy; see predict())
         keep = dh[:, 4] > conf
