@@ -85,6 +85,9 @@ struct Op {
     bool fused4 = false;          // plan decision: both 3x3 convs and this 1x1 run as c2f_fused_kernel
     int scd_pre = -1;             // OP_DWCONV 3x3 s2 closing an SCDown: index of the 1x1 conv in front of it
     bool fused5 = false;          // plan decision: that 1x1 and this depthwise conv run as scdown_fused_kernel
+    int fuse_tail = -1, tail_amax = -1;   // OP_CONV 1x1 without activation (fp32 logits): index of the dw->pw pointwise conv feeding it that can take it
+                                  // on as a third stage, and of the OP_AMAX op behind it (or -1)
+    bool fused6 = false;          // plan decision: dw -> pw -> this 1x1 (+ the class-max keys) run as conv_dwpw_kernel's TAIL form
     int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
     bool nms = false;             // OP_HEAD: conf filter + class-aware NMS (YOLOv8 / YOLO11) instead of the two-stage top-k (v10)
 };
@@ -327,6 +330,12 @@ struct DwPwParams {                              // fused depthwise 3x3 s1 -> po
     const void* w_pw; int Kpad; size_t wpw_bytes; const float* b_pw; int act_pw;   // pointwise: packed [Cout^][Kpad]
     void* y; int y_stride, y_coff; size_t y_bytes; int Cout; int out_f32;
     unsigned long long* clk;                                    // debug (YOLOP_DWPW_CLOCKS=1): per-wave phase clocks, else null
+    // TAIL form (round 3): a trailing 1x1 (the class branch's logit conv, no activation, fp32 output) runs as a third stage on the tile
+    // while it is still in LDS: y3 = W3 . act_pw(pointwise(...)) + b3; the pointwise result itself is NOT written (y is unused). When
+    // `keys` is set, the per-pixel class maximum goes out as well: keys[b*H*W + pixel] = bits of sigmoid(max_c y3) (what OP_AMAX makes)
+    const void* w3; int Kpad3; size_t w3_bytes; const float* b3; int C3;
+    float* y3; int y3_stride, y3_coff; size_t y3_bytes;
+    unsigned* keys;
 };
 bool conv_dwpw_valid(const DwPwParams& p);
 const char* conv_dwpw_kernel_name(const DwPwParams& p);

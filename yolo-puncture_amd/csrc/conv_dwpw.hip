@@ -41,7 +41,7 @@ __device__ __forceinline__ int qswz(int row) { return ((row >> 2) & 1) << 1; }
 
 // TH x 16 output pixels, BN output channels; NW waves as 2(m) x NW/2(n). NW = 8 puts two waves on every SIMD so that one
 // wave's VALU work (fragment build, SiLU) overlaps the other's MFMAs with a single set of resident weights per CU.
-template <int TH, int BN, bool OUT_F32, int NW>
+template <int TH, int BN, bool OUT_F32, int NW, bool TAIL = false>
 __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, const int tiles_h, const int tiles_w, const int ntiles,
                                                        const int G) {
     constexpr int WGM = 2, WGN = NW / 2;
@@ -67,6 +67,12 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
     unsigned char* const Wdw = Wpw + (size_t)nchunk * BN * 64;        // [nchunk*9 rows][32] bf16, rounded up to whole KiB
     const int wdw_instr = (nchunk * 9 + 15) / 16;
     float* const Bdw = (float*)(Wdw + (size_t)wdw_instr * 1024);      // [C] fp32, rounded up to whole KiB
+    // TAIL: the tile's activated pointwise result [BN/32 chunks][BM][32] bf16 (pixel operand of the third stage) and the trailing 1x1's
+    // weights [BN/32 chunks][C3R][32] bf16, C3R = C3 rounded up to 16 (rows beyond C3 are the packed matrix's zero padding)
+    unsigned char* const Ts = (unsigned char*)Bdw + (size_t)((p.C * 4 + 1023) / 1024) * 1024;
+    unsigned char* const W3s = Ts + (size_t)(BN / 32) * BM * 64;
+    const int C3R = TAIL ? ((p.C3 + 15) & ~15) : 0;
+    float* const B3s = (float*)(W3s + (size_t)(BN / 32) * C3R * 64);      // [128] fp32 (1 KiB): the trailing 1x1's bias, zero behind C3
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -118,6 +124,22 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
         for (int ii = wave; ii < b_instr; ii += NW) {
             const unsigned voff = (unsigned)(ii * 1024 + lane * 16);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (lds_void*)((unsigned char*)Bdw + ii * 1024), 16, voff, 0, 0, 0);
+        }
+        if (TAIL) {                                                    // trailing 1x1: row rg = chunk*C3R + n, k = chunk*32 + 8*c8
+            const __amdgpu_buffer_rsrc_t w3rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w3, 0, (int)p.w3_bytes, 0x00020000);
+            const int n3 = (BN / 32) * C3R / 16;
+            for (int ii = wave; ii < n3; ii += NW) {
+                const int s = ii * 64 + lane;
+                const int rg = s >> 2, pc = s & 3;
+                const int ch = rg / C3R, n = rg - ch * C3R;
+                const int c8 = pc ^ qswz(rg);
+                const unsigned voff = (unsigned)((n * p.Kpad3 + ch * 32 + c8 * 8) * 2);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(w3rs, (lds_void*)(W3s + ii * 1024), 16, voff, 0, 0, 0);
+            }
+            if (wave == 0) {                                           // bias: 512 bytes, bytes past C3 * 4 come back as zeros (descriptor bound)
+                const __amdgpu_buffer_rsrc_t b3rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.b3, 0, (int)(p.C3 * 4), 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(b3rs, (lds_void*)B3s, 16, (unsigned)(lane * 16) < 512u ? (unsigned)(lane * 16) : OOB, 0, 0, 0);
+            }
         }
     }
 
@@ -271,7 +293,15 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
                 const bool ok = pix_ok && (co < p.Cout);
                 float v[4] = {acc[a][bb][0], acc[a][bb][1], acc[a][bb][2], acc[a][bb][3]};
                 if (p.act_pw == ACT_SILU) silu4_packed(v);
-                if (OUT_F32) {
+                if (TAIL) {
+                    // the activated tile stays on chip: bf16 (the rounding the materialised tensor would have had) into the third stage's
+                    // pixel-operand image, chunk = 32 output channels of this stage = 32 k of the next
+                    __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                    const int px = (wm * (WM / 16) + bb) * 16 + fr;
+                    const int cch = wn * WN + a * 16 + fc * 4;               // channel inside the BN block
+                    const int c8 = (cch >> 3) & 3;
+                    lds_write8(Ts + (size_t)(cch >> 5) * BM * 64 + px * 64 + ((c8 ^ qswz(px)) * 16) + (fc & 1) * 8, *(const uint2*)o);
+                } else if (OUT_F32) {
                     const unsigned off = ok ? (m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 4u : OOB;
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(v[0], v[1], v[2], v[3])), yrs, off, 0, 0);
                 } else {
@@ -283,23 +313,73 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
         }
     };
 
+    // TAIL third stage, one phase (= one barrier) after the tile's epilogue put its activated result into Ts: wave w takes the tile's row w
+    // (16 pixels) and ALL C3 output channels - C3R / 16 accumulator fragments - so a lane ends up with every channel of one pixel in
+    // groups of four: bias, fp32 store, and the class maximum needs two cross-lane steps, no LDS.
+    constexpr int F3MAX = 8;                                        // C3 <= 128
+    const __amdgpu_buffer_rsrc_t y3rs = __builtin_amdgcn_make_buffer_rsrc((void*)(TAIL ? (void*)p.y3 : p.y), 0, (int)(TAIL ? p.y3_bytes : p.y_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)((TAIL && p.keys) ? (void*)p.keys : p.y), 0, (int)((TAIL && p.keys) ? (size_t)p.B * p.H * p.W * 4 : p.y_bytes), 0x00020000);
+    constexpr int ST3 = F3MAX + 1;                                  // stores a wave issues in a third-stage phase (dummies included: fixed count)
+    auto gemm3 = [&](int tile) {
+        int t = tile;
+        const int tw = t % tiles_w; t /= tiles_w;
+        const int th = t % tiles_h;
+        const int b = t / tiles_h;
+        const int ho = th * TH + wave, wo = tw * 16 + fr;
+        const bool pix_ok = (ho < p.H) && (wo < p.W);
+        const unsigned m = (unsigned)((b * p.H + ho) * p.W + wo);
+        const int nf3 = C3R >> 4, nk3 = p.Kpad3 >> 5;
+        f32x4 a3[F3MAX];
+#pragma unroll
+        for (int f = 0; f < F3MAX; ++f) a3[f] = lds_read16_async((const unsigned char*)(B3s + f * 16 + fc * 4));   // bias rides in the accumulator
+        for (int kc = 0; kc < nk3; ++kc) {
+            const int row = wave * 16 + fr;
+            const bf16x8 xf = *(const bf16x8*)(Ts + (size_t)kc * BM * 64 + swz64((unsigned)(row * 64 + fc * 16)));
+#pragma unroll
+            for (int f = 0; f < F3MAX; ++f)
+                if (f < nf3) {
+                    const int rw = kc * C3R + f * 16 + fr;
+                    const bf16x8 wf = *(const bf16x8*)(W3s + swz64((unsigned)(rw * 64 + fc * 16)));
+                    a3[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, a3[f], 0, 0, 0);
+                }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int f = 0; f < F3MAX; ++f) {
+            const int co = f * 16 + fc * 4;
+            const bool ok = pix_ok && f < nf3 && (co < p.C3);
+            if (f < nf3 && co < p.C3) mx = fmaxf(mx, fmaxf(fmaxf(a3[f][0], a3[f][1]), fmaxf(a3[f][2], a3[f][3])));
+            const unsigned off = ok ? (m * (unsigned)p.y3_stride + (unsigned)(p.y3_coff + co)) * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(a3[f][0], a3[f][1], a3[f][2], a3[f][3])), y3rs, off, 0, 0);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        {   // sigmoid(max logit) exactly as anchor_max_level_kernel forms it (head.hip): the key the top-k kernel reads
+            const float sg = 1.0f / (1.0f + expf(-mx));
+            const unsigned off = (p.keys && pix_ok && fc == 0) ? m * 4u : OOB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sg), krs, off, 0, 0);
+        }
+    };
+
     // ---- skewed pipeline over the flattened (tile, chunk) sequence --------------------------------------------------------
     unsigned long long clk[4] = {0, 0, 0, 0};
 #define DP_STAMP(i) if (p.clk) { const unsigned long long now = __builtin_amdgcn_s_memtime(); clk[i] += now - last; last = now; }
     unsigned long long last = p.clk ? __builtin_amdgcn_s_memtime() : 0ull;
     int rd_slot = 0, g = 0;
-    unsigned epmask = 0;
+    unsigned epmask = 0;                 // bit i: the wave issued its tile's stores i phases ago (S of them, TAIL: ST3)
+    constexpr int SS = TAIL ? ST3 : S;
+    static_assert(LH + 2 * SS < 64, "vmcnt immediate");
     bool first = true;
-    int prev_tile = -1, prev_c = 0;
+    int prev_tile = -1, prev_c = 0, tail_tile = -1;
     reset_acc();
     for (int tile = j0; tile < num_tiles; tile += G) {
         for (int c = 0; c < nchunk; ++c, ++g) {
             if (!first) {
                 const int k = __builtin_popcount(epmask & 3u);
                 if (k == 0) wait_vmq<LH>();
-                else if (k == 1) wait_vmq<LH + S>();
-                else wait_vmq<LH + 2 * S>();
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's A-tile writes of the previous phase are done
+                else if (k == 1) wait_vmq<LH + SS>();
+                else wait_vmq<LH + 2 * SS>();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // this wave's A-tile (and TAIL: T-tile) writes of the previous phase are done
                 __builtin_amdgcn_s_barrier();
             }
             first = false;
@@ -308,13 +388,19 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
             epmask <<= 1;
             dw_stage(c, rd_slot, g & 1);
             DP_STAMP(1)
+            if (TAIL && tail_tile >= 0) {                                  // third stage of the tile whose epilogue ran in the previous phase
+                gemm3(tail_tile);
+                tail_tile = -1;
+                epmask |= 1u;
+            }
             if (prev_tile >= 0) {
                 mfma_stage(prev_c, (g - 1) & 1);
                 DP_STAMP(2)
                 if (prev_c == nchunk - 1) {
                     epilogue(prev_tile);
                     reset_acc();
-                    epmask |= 1u;
+                    if (TAIL) tail_tile = prev_tile;
+                    else epmask |= 1u;
                     DP_STAMP(3)
                 }
             }
@@ -323,12 +409,17 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
             rd_slot = (rd_slot + 1 == NSH) ? 0 : rd_slot + 1;
         }
     }
-    // drain: MFMA + epilogue of the last chunk
+    // drain: MFMA + epilogue of the last chunk (TAIL: + its third stage behind one more barrier; nchunk >= 2, so no third stage is pending here)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     if (prev_tile >= 0) {
         mfma_stage(prev_c, (g - 1) & 1);
         epilogue(prev_tile);
+        if (TAIL) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            gemm3(prev_tile);
+        }
     }
     wait_vmq<0>();
     if (p.clk && lane == 0)
@@ -336,17 +427,21 @@ __global__ __launch_bounds__(NW * 64) void conv_dwpw_kernel(const DwPwParams p, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-static size_t dwpw_lds(int TH, int BN, int C) {
+static size_t dwpw_lds(int TH, int BN, int C, int C3 = 0) {
     const int HP = (TH + 2) * 18, H_INSTR = (HP * 4 + 63) / 64;
     const int nchunk = C / 32;
-    return (size_t)3 * H_INSTR * 1024 + (size_t)2 * TH * 16 * 64 + 1024 + (size_t)nchunk * BN * 64 +
-           (size_t)((nchunk * 9 + 15) / 16) * 1024 + (size_t)((C * 4 + 1023) / 1024) * 1024;
+    size_t b = (size_t)3 * H_INSTR * 1024 + (size_t)2 * TH * 16 * 64 + 1024 + (size_t)nchunk * BN * 64 +
+               (size_t)((nchunk * 9 + 15) / 16) * 1024 + (size_t)((C * 4 + 1023) / 1024) * 1024;
+    if (C3 > 0) b += (size_t)(BN / 32) * TH * 16 * 64 + (size_t)(BN / 32) * ((C3 + 15) / 16 * 16) * 64 + 1024;     // Ts, W3s, B3s
+    return b;
 }
+
+static bool dwpw_tail(const DwPwParams& p) { return p.w3 != nullptr; }
 
 static int dwpw_bn(const DwPwParams& p) {          // widest output-channel block whose weights fit next to the rings
     for (int bn : {128, 64}) {
         if (bn > ((p.Cout + 63) / 64) * 64) continue;
-        if (dwpw_lds(8, bn, p.C) <= 150 * 1024) return bn;
+        if (dwpw_lds(8, bn, p.C, dwpw_tail(p) ? p.C3 : 0) <= 150 * 1024) return bn;
     }
     return 0;
 }
@@ -360,26 +455,33 @@ bool conv_dwpw_valid(const DwPwParams& p) {
     // every output-channel block repeats the depthwise stage: with more than two blocks (v10-X: 320 -> 640 in 64-wide blocks) the
     // fused form costs more than the two kernels it replaces (measured 72 us vs ~35 us per pair at 40x40, bs 8)
     if ((p.Cout + bn - 1) / bn > 2) return false;
+    if (dwpw_tail(p)) {
+        // third stage: needs every channel of the pointwise result in one workgroup, >= 2 chunks (its tile image is single-buffered, read one
+        // phase after it is written), at most 128 logit channels in groups of four, fp32 output
+        if (p.Cout > bn || p.C < 64 || p.C3 <= 0 || p.C3 > 128 || (p.C3 & 3) || (p.y3_stride & 3) || (p.y3_coff & 3) || !p.y3 || !p.b3) return false;
+        if (p.Kpad3 != (p.Cout + 31) / 32 * 32 || p.y3_bytes >= (1ull << 31) || p.w3_bytes >= (1ull << 31) || (size_t)p.B * p.H * p.W * 4 >= (1ull << 31)) return false;
+    }
     return true;
 }
 
 const char* conv_dwpw_kernel_name(const DwPwParams& p) {
     const int bn = dwpw_bn(p);
+    if (dwpw_tail(p)) return bn == 128 ? "conv_dwpw_kernel<8,128,tail,8>" : "conv_dwpw_kernel<8,64,tail,8>";
     if (p.out_f32) return bn == 128 ? "conv_dwpw_kernel<8,128,true,8>" : "conv_dwpw_kernel<8,64,true,8>";
     return bn == 128 ? "conv_dwpw_kernel<8,128,false,8>" : "conv_dwpw_kernel<8,64,false,8>";
 }
 
-template <int BN, bool OUT_F32>
+template <int BN, bool OUT_F32, bool TAIL = false>
 static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t st) {
     constexpr int TH = 8, NW = 8;       // (16-row tiles - two depthwise rows per wave - measured no faster: 20 % less work per row, lost to tile imbalance)
-    const size_t sh = dwpw_lds(TH, BN, p.C);
+    const size_t sh = dwpw_lds(TH, BN, p.C, TAIL ? p.C3 : 0);
     const int tiles_h = (p.H + TH - 1) / TH, tiles_w = (p.W + 15) / 16, ntiles = (p.Cout + BN - 1) / BN;
     const int num_tiles = p.B * tiles_h * tiles_w;
     int G = 256 / ntiles;
     if (sh <= 80 * 1024 && NW == 4) G *= 2;
     if (G < 1) G = 1;
     if (G > num_tiles) G = num_tiles;
-    auto kern = conv_dwpw_kernel<TH, BN, OUT_F32, NW>;
+    auto kern = conv_dwpw_kernel<TH, BN, OUT_F32, NW, TAIL>;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
@@ -415,6 +517,7 @@ static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t st) {
 
 hipError_t launch_conv_dwpw(const DwPwParams& p, hipStream_t st) {
     const int bn = dwpw_bn(p);
+    if (dwpw_tail(p)) return bn == 128 ? launch_dwpw_t<128, false, true>(p, st) : launch_dwpw_t<64, false, true>(p, st);
     if (bn == 128) return p.out_f32 ? launch_dwpw_t<128, true>(p, st) : launch_dwpw_t<128, false>(p, st);
     return p.out_f32 ? launch_dwpw_t<64, true>(p, st) : launch_dwpw_t<64, false>(p, st);
 }

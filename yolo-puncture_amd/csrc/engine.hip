@@ -627,7 +627,26 @@ static int finish_graph_passes(yp_engine& e) {
         }
         if (!other_reader) c.fuse_pre = (int)i;
     }
-    // the final 1x1 of each head branch emits fp32 logits
+    // ---- 1x1 logit conv (no activation, fp32 output) behind a dw -> pw pair, optionally followed by the class-max op: candidates for the
+    //      third stage of conv_dwpw's TAIL form (the class branch of the v10 / YOLO11 heads: dw -> pw -> dw -> [pw -> 1x1 logits -> max]) -----
+    for (size_t i = 1; i < e.ops.size(); ++i) {
+        Op& c2 = e.ops[i];
+        const Op& c1 = e.ops[i - 1];
+        if (c2.kind != OP_CONV || c2.k != 1 || c2.s != 1 || c2.res.t >= 0 || c2.act != ACT_NONE || c2.fold_up >= 0 || c2.fuse_dw >= 0 || c2.fuse_pre >= 0) continue;
+        if (!e.tensors[c2.out.t].f32 || c2.out.coff != 0 || c2.out.C != e.tensors[c2.out.t].C) continue;
+        if (c1.kind != OP_CONV || c1.fuse_dw < 0 || c1.res.t >= 0) continue;
+        if (c2.in.t != c1.out.t || c2.in.coff != c1.out.coff || c2.in.C != c1.out.C) continue;
+        bool other_reader = false;
+        for (size_t j = 0; j < e.ops.size(); ++j) {
+            if (j == i) continue;
+            const Op& q = e.ops[j];
+            for (const View* v : {&q.in, &q.res})
+                if (v->t == c1.out.t && v->coff < c1.out.coff + c1.out.C && c1.out.coff < v->coff + v->C) other_reader = true;
+        }
+        if (other_reader) continue;
+        c2.fuse_tail = (int)i - 1;
+        if (i + 1 < e.ops.size() && e.ops[i + 1].kind == OP_AMAX && e.ops[i + 1].in.t == c2.out.t) c2.tail_amax = (int)i + 1;
+    }
     return YP_OK;
 }
 
@@ -680,7 +699,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false; e.warmed = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel", "anchor_max_level_kernel"};
-    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; o.fused5 = false; }
+    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; o.fused5 = false; o.fused6 = false; }
     static const bool no_fold = [] { const char* v = std::getenv("YOLOP_NO_FOLD"); return v && *v == '1'; }();   // A/B switch
     for (auto& o : e.ops) {
         if (o.kind != OP_CONV || o.fold_up < 0 || e.dtype != DT_BF16 || no_fold) continue;
@@ -721,6 +740,19 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         if (o.kind == OP_CONV && o.fuse_dw >= 0 && e.dtype == DT_BF16 && e.fuse) {
             const DwPwParams q = dwpw_params(e, o);
             if (conv_dwpw_valid(q)) { o.fused = true; e.ops[o.fuse_dw].skip = true; o.kernel = conv_dwpw_kernel_name(q); continue; }
+        }
+        static const bool no_tail = [] { const char* v = std::getenv("YOLOP_NO_TAIL"); return v && *v == '1'; }();   // A/B switch
+        if (o.kind == OP_CONV && o.fuse_tail >= 0 && e.dtype == DT_BF16 && e.fuse && !no_tail && e.ops[o.fuse_tail].fused) {
+            // (ops are visited in order: the pointwise conv in front has already been decided)
+            o.fused6 = true;
+            const DwPwParams q = dwpw_params(e, o);
+            if (conv_dwpw_valid(q)) {
+                e.ops[o.fuse_tail].skip = true;
+                if (o.tail_amax >= 0) e.ops[o.tail_amax].skip = true;
+                o.kernel = conv_dwpw_kernel_name(q);
+                continue;
+            }
+            o.fused6 = false;
         }
         if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
         else if (o.kind == OP_CONVT) {
@@ -770,6 +802,12 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
             if (o.kind == OP_DWCONV && o.fused5) { const Op& c1 = e.ops[o.scd_pre]; o.flops += c1.flops; o.bytes = vb(c1.in) + vb(o.out) + wb(c1) + wb(o); }
             if (o.kind != OP_CONV) continue;
             if (o.fused) { const Op& d = e.ops[o.fuse_dw]; o.flops += d.flops; o.bytes = vb(d.in) + vb(d.res) + vb(o.out) + wb(d) + wb(o); }
+            else if (o.fused6) {                    // (its pointwise conv, visited before, already carries the depthwise stage's FLOPs)
+                const Op& c1 = e.ops[o.fuse_tail];
+                const Op& d = e.ops[c1.fuse_dw];
+                o.flops += c1.flops;
+                o.bytes = vb(d.in) + vb(o.out) + wb(d) + wb(c1) + wb(o) + (o.tail_amax >= 0 ? vb(e.ops[o.tail_amax].out) : 0.0);
+            }
             else if (o.fused3) {
                 const Op &c1 = e.ops[o.fuse_pre], &st = e.ops[o.stem_op];
                 o.flops += c1.flops + st.flops; o.bytes = (double)B * H * W * 3 + vb(o.out) + wb(st) + wb(c1) + wb(o);
@@ -953,7 +991,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             return launch_stem(p, e.dtype, st);
         }
         case OP_CONV:
-            if (o.fused) return launch_conv_dwpw(dwpw_params(e, o), st);
+            if (o.fused || o.fused6) return launch_conv_dwpw(dwpw_params(e, o), st);
             if (o.fused3) return launch_frontend(front_params(e, o, a.in), st);
             if (o.fused4) return launch_c2f_fused(c2f_params(e, o), st);
             if (o.fused2) { const ConvParams q = conv_params(e, o); return launch_conv_halo_s2(q, o.cfg - 500, st); }
@@ -1110,7 +1148,7 @@ static int autotune(yp_engine& e) {
     };
     for (Op& o : e.ops) {
         if (o.kind != OP_CONV && o.kind != OP_CONVT) continue;
-        if (o.fused || o.fused2 || o.fused4 || o.skip) continue;
+        if (o.fused || o.fused2 || o.fused4 || o.fused6 || o.skip) continue;
         ConvParams p{};
         if (o.kind == OP_CONV) p = conv_params(e, o);
         else { p.Cin = o.in.C; p.Cout = o.out.C; p.ks = 1; p.Kpad = e.weights[o.widx].Kpad; p.M = e.pB * e.tensors[o.in.t].H * e.tensors[o.in.t].W;
@@ -1206,14 +1244,14 @@ static bool apply_tuning(yp_engine& e, const int* cfgs, int n) {
     if (n != (int)e.ops.size()) return false;
     for (size_t i = 0; i < e.ops.size(); ++i) {
         const Op& o = e.ops[i];
-        if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.skip) continue;
+        if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.fused6 || o.skip) continue;
         ConvParams p = tune_params(e, o);
         p.cfg = -1;
         if (!conv_cfg_usable(p, e.dtype, cfgs[i])) return false;
     }
     for (size_t i = 0; i < e.ops.size(); ++i) {
         Op& o = e.ops[i];
-        if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.skip) continue;   // a fused op keeps its own symbol / id
+        if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.fused6 || o.skip) continue;   // a fused op keeps its own symbol / id
         o.cfg = cfgs[i];
         ConvParams p = tune_params(e, o);
         p.cfg = o.cfg;
@@ -1249,6 +1287,18 @@ static void save_tune_cache(const yp_engine& e) {
 }
 
 static DwPwParams dwpw_params(const yp_engine& e, const Op& c) {
+    if (c.fused6) {            // the dw -> pw pair in front with this 1x1 (and the class-max keys) as the third stage
+        Op c1 = e.ops[c.fuse_tail];
+        c1.fused6 = false;
+        DwPwParams p = dwpw_params(e, c1);
+        const WeightDesc& w3 = e.weights[c.widx];
+        const TensorDesc& to = e.tensors[c.out.t];
+        p.w3 = w3.d_w ? w3.d_w : (const void*)1; p.Kpad3 = w3.Kpad; p.w3_bytes = w3.mat_bytes; p.b3 = w3.d_b ? w3.d_b : (const float*)1; p.C3 = c.out.C;
+        p.y3 = to.ptr ? (float*)to.ptr : (float*)1; p.y3_stride = to.C; p.y3_coff = c.out.coff; p.y3_bytes = to.bytes;
+        p.keys = c.tail_amax >= 0 ? (unsigned*)e.tensors[e.ops[c.tail_amax].out.t].ptr : nullptr;
+        p.out_f32 = 0;
+        return p;
+    }
     const Op& d = e.ops[c.fuse_dw];
     const WeightDesc &wd = e.weights[d.widx], &wp = e.weights[c.widx];
     const TensorDesc &ti = e.tensors[d.in.t], &to = e.tensors[c.out.t];
@@ -1292,6 +1342,7 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     rd.clear(); wr.clear();
     if (o.skip) return;
     if (o.fused) rd.push_back(e.ops[o.fuse_dw].in);
+    else if (o.fused6) rd.push_back(e.ops[e.ops[o.fuse_tail].fuse_dw].in);
     else if (o.fused5) rd.push_back(e.ops[o.scd_pre].in);
     else if (o.fused4) rd.push_back(View{o.in.t, o.in.coff, 2 * e.ops[o.c2f_m1].in.C});
     else if (o.fused3) { /* reads the caller's frames only */ }
@@ -1300,6 +1351,7 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     if (o.folded) rd.push_back(e.ops[o.fold_up].in);      // (besides the concat buffer, whose skip part it still reads)
     if (o.res.t >= 0) rd.push_back(o.res);
     if (o.out.t >= 0) wr.push_back(o.out);
+    if (o.fused6 && o.tail_amax >= 0) wr.push_back(e.ops[o.tail_amax].out);
     if (o.kind == OP_HEAD)
         for (int l = 0; l < 3; ++l) {
             if (o.box[l].t >= 0) rd.push_back(o.box[l]);
@@ -1970,7 +2022,7 @@ int yp_debug_host_selftest(yp_engine* e) {
     for (const Op& o : e->ops) {
         if (o.skip) continue;
         if (o.kind == OP_CONV) {
-            if (o.fused) acc += (size_t)dwpw_params(*e, o).Cout;
+            if (o.fused || o.fused6) acc += (size_t)dwpw_params(*e, o).Cout;
             else if (o.fused3) acc += (size_t)front_params(*e, o, nullptr).C2;
             else if (o.fused4) acc += (size_t)c2f_params(*e, o).Cout;
             else acc += (size_t)conv_params(*e, o).Cout;
