@@ -77,7 +77,14 @@ struct yp_engine {
     // autotuner results per input shape seen so far: switching between shapes re-plans but does not re-tune
     struct Tuned { int cfg; std::string kernel; };
     std::map<std::array<int, 3>, std::vector<Tuned>> tuned;
-    struct Key { int B = 0, H = 0, W = 0; const void* in = nullptr; } gkey;   // what the captured graph is specialised on
+    struct Key { int B = 0, H = 0, W = 0; const void* in = nullptr; const void* det = nullptr; const void* idx = nullptr; const void* coeff = nullptr; } gkey;   // what the captured graph is specialised on
+    // Output mode of the replay. Direct (the start): the graph writes the caller's buffers, which most callers keep from call to call
+    // (bench.py, predictor.py's per-shape output cache) - no copy kernel behind the graph. A caller that brings NEW output buffers would
+    // force capture + instantiate per call: the second change of pointers switches this engine to engine-owned results + a 0.3 MB
+    // copy-out for good.
+    bool direct_out = true;
+    int out_changes = 0;
+    hipEvent_t ev_done = nullptr;         // recorded behind the last replay on the stream it ran on (an executable is never destroyed under the GPU)
     // engine-owned results of the replayed graph: the graph never references the caller's output buffers (they change from
     // call to call in ordinary use, and every change would mean capture + instantiate + destroy); yp_forward copies the
     // ~0.3 MB out behind the replay
@@ -1646,6 +1653,7 @@ int yp_destroy(yp_engine* e) {
     if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+    if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     for (auto ls : e->lane_streams) (void)hipStreamDestroy(ls);
     for (auto ev : e->lane_events) (void)hipEventDestroy(ev);
@@ -1889,16 +1897,25 @@ static int forward_eager(yp_engine* e, const RunArgs& a, hipStream_t st) {
     return rc != YP_OK ? rc : run_all(*e, a, st);
 }
 
-// hipGraph replay on the engine's own stream, ordered against the caller's stream by events. The graph is specialised on
-// the plan and on the INPUT pointer only (frames are read in place); results land in engine-owned buffers.
+// hipGraph replay ON THE CALLER'S STREAM (round 3; before: on the engine's own stream behind an event pair - the caller's stream then waited
+// for the replay and the next replay waited for the caller's stream, a ping-pong that left the GPU idle for ~20 us between steps, and a copy
+// kernel moved the results). The graph is captured on the engine's own stream (capture needs a stream nothing else uses) but an executable
+// graph launches on any stream; its lanes are internal fork / join edges. It is specialised on the plan, the INPUT pointer and - in direct
+// mode - the output pointers.
 static int forward_replay(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out, float* coeff_out, hipStream_t st) {
     int rc;
     const bool seg = e->desc.task == YP_TASK_SEGMENT;
-    RunArgs ag{in_dev, e->o_det, e->o_idx, seg ? e->o_coeff : nullptr};
-    if (!e->gexec || e->gkey.B != B || e->gkey.H != H || e->gkey.W != W || e->gkey.in != (const void*)in_dev) {
+    float* const cf = (coeff_out && seg) ? coeff_out : nullptr;
+    const bool same_plan = e->gexec && e->gkey.B == B && e->gkey.H == H && e->gkey.W == W && e->gkey.in == (const void*)in_dev;
+    if (e->direct_out && same_plan && (e->gkey.det != det_out || e->gkey.idx != idx_out || e->gkey.coeff != cf) && ++e->out_changes >= 2)
+        e->direct_out = false;                        // this caller rotates its output buffers: engine-owned results + copy-out from now on
+    static const bool own = [] { const char* v = std::getenv("YOLOP_REPLAY_OWN_STREAM"); return v && *v == '1'; }();   // A/B switch: round 2's path
+    const bool direct = !own && e->direct_out && det_out && idx_out && (!seg || cf);
+    RunArgs ag = direct ? RunArgs{in_dev, det_out, idx_out, cf} : RunArgs{in_dev, e->o_det, e->o_idx, seg ? e->o_coeff : nullptr};
+    if (!same_plan || e->gkey.det != ag.det || e->gkey.idx != ag.idx || e->gkey.coeff != ag.coeff) {
         if (e->gexec) {
             // the previous executable may still be running (replays are asynchronous): never destroy it under the GPU
-            HIPCHK(hipStreamSynchronize(e->own_stream));
+            if (e->ev_done) HIPCHK(hipEventSynchronize(e->ev_done));
             (void)hipGraphExecDestroy(e->gexec);
             e->gexec = nullptr;
         }
@@ -1910,19 +1927,24 @@ static int forward_replay(yp_engine* e, const uint8_t* in_dev, int B, int H, int
         if (ce != hipSuccess) return fail(YP_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
         HIPCHK(hipGraphInstantiate(&e->gexec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
-        e->gkey.B = B; e->gkey.H = H; e->gkey.W = W; e->gkey.in = in_dev;
+        e->gkey.B = B; e->gkey.H = H; e->gkey.W = W; e->gkey.in = in_dev; e->gkey.det = ag.det; e->gkey.idx = ag.idx; e->gkey.coeff = ag.coeff;
     }
-    HIPCHK(hipEventRecord(e->ev_in, st));
-    HIPCHK(hipStreamWaitEvent(e->own_stream, e->ev_in, 0));
-    rc = push_nms_params(e, e->own_stream);
+    hipStream_t rs = st;
+    if (own) {
+        rs = e->own_stream;
+        HIPCHK(hipEventRecord(e->ev_in, st));
+        HIPCHK(hipStreamWaitEvent(rs, e->ev_in, 0));
+    }
+    rc = push_nms_params(e, rs);
     if (rc != YP_OK) return rc;
-    HIPCHK(hipGraphLaunch(e->gexec, e->own_stream));
-    {
+    HIPCHK(hipGraphLaunch(e->gexec, rs));
+    if (!direct) {
         const size_t rows = (size_t)B * e->desc.max_det;
-        HIPCHK(launch_copy_out(e->o_det, det_out, e->o_idx, idx_out, e->o_coeff, (coeff_out && seg) ? coeff_out : nullptr, rows, e->own_stream));
+        HIPCHK(launch_copy_out(e->o_det, det_out, e->o_idx, idx_out, e->o_coeff, cf, rows, rs));
     }
-    HIPCHK(hipEventRecord(e->ev_out, e->own_stream));
-    HIPCHK(hipStreamWaitEvent(st, e->ev_out, 0));
+    if (!e->ev_done) HIPCHK(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(e->ev_done, rs));
+    if (own) HIPCHK(hipStreamWaitEvent(st, e->ev_done, 0));
     return YP_OK;
 }
 
@@ -2113,7 +2135,7 @@ int yp_set_graph(yp_engine* e, int enable) {
         // only a change of the LANE mode invalidates the captured executable; switching between eager launches and replay keeps it, so a
         // caller that alternates one-frame calls (eager) with batches (replay) pays neither a sync nor a re-capture
         HIPCHK(hipSetDevice(e->device));
-        HIPCHK(hipStreamSynchronize(e->own_stream));
+        if (e->ev_done) HIPCHK(hipEventSynchronize(e->ev_done));
         (void)hipGraphExecDestroy(e->gexec);
         e->gexec = nullptr;
         e->auto_replay.clear();
