@@ -68,18 +68,16 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwParams p, cons
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(Wd + ii * 1024), 16, voff, 0, 0, 0);
     }
 
-    // per-lane constants of the diagonal fragments (same construction as conv_dwpw.hip)
-    unsigned dmask[2][4];
+    // per-lane constants of the diagonal fragments (same construction as conv_dwpw.hip, round 3: TWO taps per MFMA - k < 16 carries 16
+    // channels of tap A, k >= 16 the same 16 channels of tap B; lane group fc reads its 16 bytes from the halo pixel of tap (fc >> 1))
+    unsigned dmask[4];
     {
         const bool valid = (fc & 1) == (fr >> 3);
         const unsigned hw = (fr & 1) ? 0xffff0000u : 0x0000ffffu;
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) dmask[h][q] = (valid && h == (fc >> 1) && q == ((fr & 7) >> 1)) ? hw : 0u;
+        for (int q = 0; q < 4; ++q) dmask[q] = (valid && q == ((fr & 7) >> 1)) ? hw : 0u;
     }
-    const int dch = (fr + 16 * (fc >> 1)) & ~1;
-
+    const int tapsel = fc >> 1;
     const int PW = p.W >> 2, NP = PW * (p.H >> 2);
     const int nslot = ((NP + psplit - 1) / psplit + 3) >> 2;      // patch slots a wave of this workgroup can have
     f32x4 acc[DWM_MAXP][2];
@@ -104,26 +102,30 @@ __global__ __launch_bounds__(256) void dwconv_mfma_kernel(const DwParams p, cons
     __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0xF << 8));           // vmcnt(0)
     __builtin_amdgcn_s_barrier();
 
-    for (int ky = 0; ky < KS; ++ky) {
-        bf16x8 wd[KS][2];
+    // the KS*KS taps in pairs (2j, 2j+1) (the last one alone: its B half gets zero weights): per pair two fragments (channel halves), per
+    // patch two fragment reads + two MFMAs - 25 x 2 MFMAs per patch instead of 49 x 2
+    constexpr int NT = KS * KS, NPR = (NT + 1) / 2;
+    for (int j = 0; j < NPR; ++j) {
+        const int tA = 2 * j, tB = (2 * j + 1 < NT) ? 2 * j + 1 : tA;
+        const int t = tapsel ? tB : tA;
+        const int ky = t / KS, kx = t - ky * KS;
+        const int toff = ky * P + kx;                               // this lane's tap offset in halo pixels
+        bf16x8 wd[2];
 #pragma unroll
-        for (int kx = 0; kx < KS; ++kx) {
-            const unsigned wbits = *(const unsigned*)(Wd + (ky * KS + kx) * 64 + dch * 2);
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint4 v = make_uint4(wbits & dmask[h][0], wbits & dmask[h][1], wbits & dmask[h][2], wbits & dmask[h][3]);
-                wd[kx][h] = *(const bf16x8*)&v;
-            }
+        for (int h = 0; h < 2; ++h) {
+            unsigned wbits = *(const unsigned*)(Wd + t * 64 + ((fr + 16 * h) & ~1) * 2);
+            if (tapsel && 2 * j + 1 >= NT) wbits = 0u;
+            const uint4 v = make_uint4(wbits & dmask[0], wbits & dmask[1], wbits & dmask[2], wbits & dmask[3]);
+            wd[h] = *(const bf16x8*)&v;
         }
 #pragma unroll
         for (int i = 0; i < DWM_MAXP; ++i) {
             if (SPLIT && i >= nslot) break;                     // (workgroup-uniform: slots beyond this workgroup's share of the patches)
+            const int hp = pbase[i] + toff;
 #pragma unroll
-            for (int kx = 0; kx < KS; ++kx) {
-                const int hp = pbase[i] + ky * P + kx;
-                const bf16x8 xf = *(const bf16x8*)(Xs + swz64((unsigned)(hp * 64 + fc * 16)));
-                acc[i][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[kx][0], xf, acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[kx][1], xf, acc[i][1], 0, 0, 0);
+            for (int h = 0; h < 2; ++h) {
+                const bf16x8 xf = *(const bf16x8*)(Xs + swz64((unsigned)(hp * 64 + (2 * h + (fc & 1)) * 16)));
+                acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[h], xf, acc[i][h], 0, 0, 0);
             }
         }
     }
