@@ -9,3 +9,25 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+import os
+
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def _side_stream():
+    """YOLOP_TEST_STREAM=1: run every test under a non-default torch stream (the engine launches its graph on the caller's stream
+    when that is not the legacy null stream)."""
+    if os.environ.get("YOLOP_TEST_STREAM") != "1":
+        yield
+        return
+    import torch
+    if not torch.cuda.is_available():
+        yield
+        return
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        yield
+    torch.cuda.synchronize()

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <fcntl.h>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -1590,12 +1591,17 @@ const char* yp_last_error(void) { return g_err; }
 #include <unistd.h>
 static struct sigaction g_prev_sa[3];
 static const int g_fatal_sigs[3] = {SIGSEGV, SIGABRT, SIGBUS};
+static int g_fatal_fd = -1;                      // YOLOP_SEGV_FILE=<path>: the native backtrace is appended there as well
 static void yp_fatal_handler(int sig) {
     void* frames[64];
     const int n = backtrace(frames, 64);
     const char* msg = sig == SIGSEGV ? "\n[yolop] SIGSEGV - native backtrace:\n" : sig == SIGABRT ? "\n[yolop] SIGABRT - native backtrace:\n" : "\n[yolop] SIGBUS - native backtrace:\n";
     (void)!write(2, msg, strlen(msg));
     backtrace_symbols_fd(frames, n, 2);
+    if (g_fatal_fd >= 0) {                        // (a test runner that captures fd 2 loses the lines above with the process)
+        (void)!write(g_fatal_fd, msg, strlen(msg));
+        backtrace_symbols_fd(frames, n, g_fatal_fd);
+    }
     // hand over to whoever was installed before us (Python's faulthandler prints the interpreter stack), else the default action
     for (int i = 0; i < 3; ++i)
         if (g_fatal_sigs[i] == sig) (void)sigaction(sig, &g_prev_sa[i], nullptr);
@@ -1607,6 +1613,7 @@ static void install_fatal_handlers() {
     done = true;
     const char* tr = std::getenv("YOLOP_SEGV_TRACE");
     if (tr && *tr == '0') return;
+    if (const char* f = std::getenv("YOLOP_SEGV_FILE")) g_fatal_fd = open(f, O_WRONLY | O_CREAT | O_APPEND, 0644);
     void* warm[2];
     (void)backtrace(warm, 2);                    // loads libgcc now: the first backtrace() call allocates, which a handler must not
     for (int i = 0; i < 3; ++i) {
@@ -1897,7 +1904,7 @@ static int forward_eager(yp_engine* e, const RunArgs& a, hipStream_t st) {
     return rc != YP_OK ? rc : run_all(*e, a, st);
 }
 
-// hipGraph replay ON THE CALLER'S STREAM (round 3; before: on the engine's own stream behind an event pair - the caller's stream then waited
+// hipGraph replay ON THE CALLER'S STREAM when that is not the legacy null stream (round 3; before: on the engine's own stream behind an event pair - the caller's stream then waited
 // for the replay and the next replay waited for the caller's stream, a ping-pong that left the GPU idle for ~20 us between steps, and a copy
 // kernel moved the results). The graph is captured on the engine's own stream (capture needs a stream nothing else uses) but an executable
 // graph launches on any stream; its lanes are internal fork / join edges. It is specialised on the plan, the INPUT pointer and - in direct
@@ -1909,8 +1916,12 @@ static int forward_replay(yp_engine* e, const uint8_t* in_dev, int B, int H, int
     const bool same_plan = e->gexec && e->gkey.B == B && e->gkey.H == H && e->gkey.W == W && e->gkey.in == (const void*)in_dev;
     if (e->direct_out && same_plan && (e->gkey.det != det_out || e->gkey.idx != idx_out || e->gkey.coeff != cf) && ++e->out_changes >= 2)
         e->direct_out = false;                        // this caller rotates its output buffers: engine-owned results + copy-out from now on
-    static const bool own = [] { const char* v = std::getenv("YOLOP_REPLAY_OWN_STREAM"); return v && *v == '1'; }();   // A/B switch: round 2's path
-    const bool direct = !own && e->direct_out && det_out && idx_out && (!seg || cf);
+    static const int own_mode = [] { const char* v = std::getenv("YOLOP_REPLAY_OWN_STREAM"); return v ? atoi(v) : 0; }();   // A/B switch: 1 = round 2's path, 2 = own stream + direct outputs
+    // The legacy NULL stream is the exception: hipGraphLaunch of a re-captured multi-lane graph on stream 0 faulted inside the runtime
+    // (ROCm 7.2; deterministic in tests/test_gpu_fullsize.py, not under a non-default stream, not with the engine's own stream). A caller
+    // on the null stream therefore gets the engine's own stream + the event pair; bench.py runs its steps under a side stream.
+    const bool own = own_mode != 0 || st == nullptr;
+    const bool direct = own_mode != 1 && e->direct_out && det_out && idx_out && (!seg || cf);
     RunArgs ag = direct ? RunArgs{in_dev, det_out, idx_out, cf} : RunArgs{in_dev, e->o_det, e->o_idx, seg ? e->o_coeff : nullptr};
     if (!same_plan || e->gkey.det != ag.det || e->gkey.idx != ag.idx || e->gkey.coeff != ag.coeff) {
         if (e->gexec) {
