@@ -95,6 +95,14 @@ def test_per_op_bf16_teacher_forced(variant, seg, shape, cfg, fuse, monkeypatch)
     _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, 80)
 
 
+@pytest.mark.parametrize("variant,seg,shape", [("s", True, (3, 96, 160)), ("n", False, (2, 256, 384)), ("s", False, (1, 480, 608))])
+def test_per_op_bf16_tail_form(variant, seg, shape, monkeypatch):
+    """conv_dwpw's TAIL form (YOLOP_TAIL=1: the class branch's logit conv and the class-max keys as a third stage of the last dw -> pw pair;
+    opt-in because the replayed step is not faster with it): same per-op contract, keys = sigmoid(max logit) of the kernel's own logits."""
+    monkeypatch.setenv("YOLOP_TAIL", "1")
+    _per_op_bf16(variant, seg, shape, -1, True, monkeypatch, 80, want_tail=True)
+
+
 @pytest.mark.parametrize("variant,seg,shape,nc", [("s", True, (3, 96, 160), 1), ("s", True, (3, 96, 160), 3), ("n", False, (2, 256, 384), 1),
                                                   ("s", False, (1, 160, 192), 3)])
 def test_per_op_bf16_small_nc(variant, seg, shape, nc, monkeypatch):
@@ -104,7 +112,7 @@ def test_per_op_bf16_small_nc(variant, seg, shape, nc, monkeypatch):
     _per_op_bf16(variant, seg, shape, -1, True, monkeypatch, nc)
 
 
-def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc):
+def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc, want_tail=False):
     """bf16 kernels one at a time: every op consumes the ORACLE's (bf16emu) tensors - after each op its output
     slice is overwritten with the oracle's tap - so the only admissible difference is the bf16 rounding of an
     fp32 sum taken in a different order: <= 1 bf16 ulp per element, on a small fraction of the elements.
@@ -202,6 +210,7 @@ def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc):
     load_library().yp_debug_force_conv_cfg(-1)
     assert len(rows) > 50
     assert nfused == 0 if not fuse else (nfused > 0 or shape != (2, 256, 384) or nc != 80)
+    assert ntail > 0 if want_tail else ntail == 0
 
 
 def _final_report(res, ref, k):

@@ -62,6 +62,7 @@ struct yp_engine {
     bool graph_auto = false;              // yp_set_graph(3): replay or eager per plan, whichever a one-off timing finds faster
     std::map<std::array<int, 3>, bool> auto_replay;
     bool fuse = true;             // dw->pw fusion (YOLOP_NO_FUSE=1 disables, for A/B)
+    bool tail = false;            // conv_dwpw TAIL form (YOLOP_TAIL=1 at yp_create enables; see make_plan)
     bool tune = true;             // plan-time autotuning of the conv tile configuration
     hipStream_t own_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
@@ -749,8 +750,12 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
             const DwPwParams q = dwpw_params(e, o);
             if (conv_dwpw_valid(q)) { o.fused = true; e.ops[o.fuse_dw].skip = true; o.kernel = conv_dwpw_kernel_name(q); continue; }
         }
-        static const bool no_tail = [] { const char* v = std::getenv("YOLOP_NO_TAIL"); return v && *v == '1'; }();   // A/B switch
-        if (o.kind == OP_CONV && o.fuse_tail >= 0 && e.dtype == DT_BF16 && e.fuse && !no_tail && e.ops[o.fuse_tail].fused) {
+        // TAIL form (logit conv + class-max keys as a third stage of the last dw -> pw pair): opt-in, YOLOP_TAIL=1. Alone it takes 33 us less
+        // than the three launches it replaces (213 -> 180 us over the P3 / P4 class branches, -105 MB of HBM traffic), but in the replayed
+        // graph the step is 0.7 % SLOWER with it (1.936 vs 1.922 ms, same box, three alternating runs): the 1x1 conv and the max pass it
+        // removes were HBM-bound and ran beside the VALU-bound kernels of the other head lanes for free, while the longer fused kernel holds
+        // its statically assigned CUs for longer.
+        if (o.kind == OP_CONV && o.fuse_tail >= 0 && e.dtype == DT_BF16 && e.fuse && e.tail && e.ops[o.fuse_tail].fused) {
             // (ops are visited in order: the pointwise conv in front has already been decided)
             o.fused6 = true;
             const DwPwParams q = dwpw_params(e, o);
@@ -1637,6 +1642,7 @@ int yp_create(const yp_model_desc* desc, int device, yp_engine** out) {
     std::unique_ptr<yp_engine> e(new yp_engine());
     e->desc = *desc; e->device = device; e->dtype = desc->dtype;
     { const char* nf = std::getenv("YOLOP_NO_FUSE"); e->fuse = !(nf && *nf == '1'); }
+    { const char* tf = std::getenv("YOLOP_TAIL"); e->tail = tf && *tf == '1'; }
     int rc = build_graph(*e);
     if (rc != YP_OK) return rc;
     for (const Op& o : e->ops)
