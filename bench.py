@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (rehearsal of the N>1 path on a 1-GPU box; launch under torch.distributed.run)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-dense-head", action="store_true", help="skip the comparison leg that times the same step with every head branch dense")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the bounded CPU-baseline sample")
     return ap.parse_args()
 
@@ -185,6 +186,10 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     value = world * B * a.steps / dt
 
+    head_note = {"box_branch": "dense (YOLOP_DENSE_HEAD=1)" if os.environ.get("YOLOP_DENSE_HEAD") == "1" else
+                 "evaluated at the positions the top-k winners' 3x3 neighbourhoods cover (head_branch.hip): the rows v10postprocess gathers, "
+                 "same values as the dense maps up to fp32 summation order; dense_head = the same step with every branch dense"}
+
     def line(roof, cpu, partial):
         d = {
             "metric": "images/sec", "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
@@ -194,7 +199,8 @@ def main():
                                    f"u8 frames resident in HBM -> [B,300,6] detections"
                                    + (", RCCL all-gather of detections" if world > 1 else ""),
                        "global_batch": world * B, "imgsz": S, "parallelism": f"frame-shard x{world}",
-                       "weights": "seeded synthetic (SURVEY 8d)", "hipgraph": not a.no_graph},
+                       "weights": "seeded synthetic (SURVEY 8d)", "hipgraph": not a.no_graph,
+                       "head": head_note},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if partial:
@@ -247,6 +253,33 @@ def main():
                                          gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)) for n, v in by_kernel.items()})
         except Exception as ex:      # (a failed diagnostic pass must not cost the measured line)
             roof = {"error": f"{type(ex).__name__}: {ex}"}
+
+    if rank == 0 and world == 1 and not a.no_dense_head and not a.no_graph and a.dtype == "bf16" and os.environ.get("YOLOP_DENSE_HEAD") != "1":
+        # comparison leg, outside the timed region: the same step with the box branch dense over all 8400 anchors (what round 2 measured),
+        # and how far the two engines' detections are apart on these frames
+        try:
+            os.environ["YOLOP_DENSE_HEAD"] = "1"                # read by yp_create
+            try:
+                de = Engine(a.variant, 80, a.seg, a.dtype, local, state=st)
+            finally:
+                del os.environ["YOLOP_DENSE_HEAD"]
+            out_d = {k: (torch.empty_like(v) if v is not None else None) for k, v in out.items()}
+            de.set_graph(True)
+            with torch.cuda.stream(side):
+                for _ in range(max(a.warmup, 3)):
+                    de.forward(frames, out_d)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    de.forward(frames, out_d)
+                torch.cuda.synchronize(dev)
+                dt_d = time.perf_counter() - t0
+            head_note["dense_head"] = {"ms_per_step": round(dt_d / a.steps * 1e3, 4), "value": round(B * a.steps / dt_d, 1),
+                                       "same_anchors_classes_scores": bool(torch.equal(out["idx"], out_d["idx"]) and torch.equal(out["det"][..., 4:], out_d["det"][..., 4:])),
+                                       "max_box_difference_px": round(float((out["det"][..., :4] - out_d["det"][..., :4]).abs().max()), 4)}
+            de.close()
+        except Exception as ex:
+            head_note["dense_head"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     cpu = None
     if want_cpu:

@@ -225,6 +225,19 @@ int yp_debug_ablation(int v);
    [0] start, [1] keys loaded, [2] stage-1 lower bound found, [3] stage-1 select done, [4] stage-2 candidates scanned,
    [5] stage-2 select done, [6] decoded; [7] = stage-2 rounds << 32 | candidates that entered the last round's select. */
 int yp_debug_head_clocks(uint64_t* out8);
+/* The same for the position kernel of the winners-only head (workgroup 0's first tile, last launch): [0] tile start, [1] position list read,
+   [2] first patch plane landed, [3] all channel chunks done, [4] activations stored; [5] = level << 32 | channel chunks of that tile,
+   [6] = tiles of the launch (64 positions each), [7] = listed positions of the launch (all levels, all images). */
+int yp_debug_head_branch_clocks(uint64_t* out8);
+/* Winners-only head (the default for bf16 YOLOv10 engines whose branch width is 64 / 32 channels; YOLOP_DENSE_HEAD=1 at yp_create keeps
+   every branch dense): the box branch `one2one_cv2.*` - and the coefficient branch `cv4.*` of the seg head - are evaluated only for the
+   max_det anchors the class scores select, which are the only ones whose boxes the reference's v10postprocess gathers ([U] SURVEY A.6;
+   inside `.predict`, yolo_seg/app.py:91): the first 3x3 once per distinct position of the winners' 3x3 neighbourhoods, the second 3x3 and
+   the 1x1 at the winners. Same inputs, weights and rounding points as the dense convolutions, so the same numbers up to fp32 summation
+   order. This hook copies what the last forward left: sel_host int32 [B][512] (stage-1 winners, anchor ids by rank),
+   box_host float [B][max_det][64] and coeff_host float [B][max_det][32] (rows by rank; any may be NULL).
+   Returns bit 0: box rows are winners-only, bit 1: coefficient rows are; 0 = dense head. */
+int yp_debug_head_winners(yp_engine* e, int32_t* sel_host, float* box_host, float* coeff_host);
 /* phase stamps of yp_mask_contours (mask 0): [0..6] 100-MHz ticks at box / bit image / candidates / trace / emit / hull / end, [8] candidates,
    [9] points of the winning contour, [10], [11] bounding box width, height */
 int yp_debug_contour_clocks(uint64_t* out12);

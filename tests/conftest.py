@@ -9,6 +9,13 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fatal signal inside the native library leaves its C backtrace here (pytest captures fd 2 and loses it with the process)
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        os.environ.setdefault("YOLOP_SEGV_FILE", os.path.join(out, "native_backtrace.txt"))
+    except OSError:
+        pass
 
 
 import os

@@ -25,7 +25,10 @@ def test_header_symbols_are_exported():
 
 
 @pytest.mark.parametrize("v,seg", [("n", True), ("s", False), ("m", True), ("b", False), ("l", False), ("x", False)])
-def test_graph_matches_folded_weights_and_flops(v, seg):
+def test_graph_matches_folded_weights_and_flops(v, seg, monkeypatch):
+    # the graph as the reference defines it: every branch of the head dense (the default plan evaluates the box / coefficient branches on the
+    # top-k winners only and therefore executes fewer FLOPs: checked at the end)
+    monkeypatch.setenv("YOLOP_DENSE_HEAD", "1")
     e = Engine(v, 80, seg, "bf16", 0)
     exp = dict(e.expected_weights())
     got = {}
@@ -42,6 +45,21 @@ def test_graph_matches_folded_weights_and_flops(v, seg):
     # the host-only self-check of the executor (parameter blocks, kernel symbols, lane schedule invariants) for both plans
     assert e.lib.yp_debug_host_selftest(e._h) > 0
     e.plan(1, 640, 640)
+    assert e.lib.yp_debug_host_selftest(e._h) > 0
+    e.close()
+    # default plan: winners-only head - the nine box-branch convolutions (and the coefficient branch's where its width is supported) launch
+    # nothing, the head op carries their work on max_det winners per frame
+    monkeypatch.delenv("YOLOP_DENSE_HEAD")
+    e = Engine(v, 80, seg, "bf16", 0)
+    ops3 = e.plan(1, 640, 640)
+    box = [o for o in ops3 if ".one2one_cv2." in o["name"]]
+    assert len(box) == 9
+    if v == "x":      # 80-channel branch (padded taps): stays dense
+        assert all(o["kernel"] != "-" for o in box) and "head_pos_kernel" not in ops3[-1]["kernel"]
+    else:
+        assert all(o["kernel"] == "-" and o["flops"] == 0 for o in box)
+        assert "head_pos_kernel" in ops3[-1]["kernel"] and ops3[-1]["flops"] > 0
+        assert sum(o["flops"] for o in ops3) < sum(o["flops"] for o in ops)
     assert e.lib.yp_debug_host_selftest(e._h) > 0
     e.close()
 

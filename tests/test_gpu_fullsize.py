@@ -20,13 +20,24 @@ pytestmark = pytest.mark.gpu
 
 
 def _logits(eng, B, H, W, nc):
-    """engine's fp32 head logits -> box [B,64,A], cls [B,nc,A] in the oracle's anchor order (P3,P4,P5 row-major)."""
+    """engine's fp32 head logits -> box [B,64,A], cls [B,nc,A] in the oracle's anchor order (P3,P4,P5 row-major). With the winners-only
+    head (the default) the box logits exist only at the stage-1 winners: their rows are scattered into a zero map - the oracle's own
+    top-k, which looks at the class scores alone, then picks exactly those anchors (a non-winner's box is never read)."""
     box, cls = [], []
     for l in range(3):
-        b = eng.read_tensor(eng.find_tensor(f"model.23.one2one_cv2.{l}.2"))      # [B,h,w,64]
         c = eng.read_tensor(eng.find_tensor(f"model.23.one2one_cv3.{l}.2"))
-        box.append(b.reshape(B, -1, 64).permute(0, 2, 1))
         cls.append(c.reshape(B, -1, nc).permute(0, 2, 1))
+    mode, sel, rows, _ = eng.head_winners(B)
+    if mode & 1:
+        A = sum((H // s) * (W // s) for s in (8, 16, 32))
+        bl = torch.zeros((B, A, 64))
+        k = min(eng.max_det, A)
+        bi = torch.arange(B)[:, None].expand(B, k)
+        bl[bi, sel[:, :k].long()] = rows[:, :k]
+        return bl.permute(0, 2, 1).contiguous(), torch.cat(cls, 2).contiguous()
+    for l in range(3):
+        b = eng.read_tensor(eng.find_tensor(f"model.23.one2one_cv2.{l}.2"))      # [B,h,w,64]
+        box.append(b.reshape(B, -1, 64).permute(0, 2, 1))
     return torch.cat(box, 2).contiguous(), torch.cat(cls, 2).contiguous()
 
 

@@ -95,10 +95,11 @@ def test_per_op_bf16_teacher_forced(variant, seg, shape, cfg, fuse, monkeypatch)
     _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, 80)
 
 
-@pytest.mark.parametrize("variant,seg,shape", [("s", True, (3, 96, 160)), ("n", False, (2, 256, 384)), ("s", False, (1, 480, 608))])
+@pytest.mark.parametrize("variant,seg,shape", [("s", True, (1, 256, 320)), ("s", False, (2, 256, 384)), ("s", False, (1, 480, 608))])
 def test_per_op_bf16_tail_form(variant, seg, shape, monkeypatch):
     """conv_dwpw's TAIL form (YOLOP_TAIL=1: the class branch's logit conv and the class-max keys as a third stage of the last dw -> pw pair;
-    opt-in because the replayed step is not faster with it): same per-op contract, keys = sigmoid(max logit) of the kernel's own logits."""
+    opt-in because the replayed step is not faster with it): same per-op contract, keys = sigmoid(max logit) of the kernel's own logits.
+    (The form needs a 128-wide class branch - variant s at nc = 80 - and level maps that fill the kernel's 8x16 tiles.)"""
     monkeypatch.setenv("YOLOP_TAIL", "1")
     _per_op_bf16(variant, seg, shape, -1, True, monkeypatch, 80, want_tail=True)
 
@@ -255,13 +256,18 @@ def test_end_to_end_fp32(variant, seg, shape, nc):
         assert_within_noise_floor("prototypes", res["proto"], nchw_to_nhwc(ref["proto"]), nchw_to_nhwc(ref64["proto"]), 1e-3)
 
 
-@pytest.mark.parametrize("variant,seg,shape", [("n", True, (2, 96, 128)), ("s", False, (2, 320, 320))])
-def test_end_to_end_bf16_accuracy(variant, seg, shape):
+@pytest.mark.parametrize("variant,seg,shape,dense", [("n", True, (2, 96, 128), True), ("s", False, (2, 320, 320), True),
+                                                       ("n", True, (2, 96, 128), False), ("s", False, (2, 320, 320), False), ("s", True, (3, 160, 192), False)])
+def test_end_to_end_bf16_accuracy(variant, seg, shape, dense, monkeypatch):
     """Chained bf16 forward. Two faithful bf16 implementations decorrelate over ~60 re-rounded layers, so the
     engine is not compared with the bf16emu oracle element by element; instead both are measured against the fp32
-    oracle (the reference's CPU path) on the head's raw logits for ALL anchors: the engine's error must not exceed
-    1.25x the error of the bf16-emulating oracle (i.e. it is as accurate as bf16 storage allows)."""
+    oracle (the reference's CPU path) on the head's raw logits: the engine's error must not exceed 1.25x the error of the
+    bf16-emulating oracle (i.e. it is as accurate as bf16 storage allows). dense: every branch of the head dense (YOLOP_DENSE_HEAD=1), all
+    anchors compared; else the default winners-only head - box logits (and mask coefficients) exist at the stage-1 winners only and are
+    compared there, row by row, with the oracle's maps at those anchors."""
     from oracle.yolov10_oracle import Oracle
+    if dense:
+        monkeypatch.setenv("YOLOP_DENSE_HEAD", "1")
     st, im = make_case(variant, 80, seg, 0, shape)
     t32, t16 = {}, {}
     Oracle(st, variant, 80, seg, "fp32", tap=lambda n, x: t32.__setitem__(n, x.float())).forward(im)
@@ -270,9 +276,16 @@ def test_end_to_end_bf16_accuracy(variant, seg, shape):
     eng.forward(im.cuda())
     torch.cuda.synchronize()
     rep = {}
-    names = [f"model.23.one2one_cv2.{l}.2" for l in range(3)] + [f"model.23.one2one_cv3.{l}.2" for l in range(3)]
+    B = shape[0]
+    mode, sel, rows, cfrows = eng.head_winners(B)
+    assert (mode == 0) == dense, mode
+    names = [f"model.23.one2one_cv3.{l}.2" for l in range(3)]
+    if dense or not (mode & 1):
+        names += [f"model.23.one2one_cv2.{l}.2" for l in range(3)]
     if seg:
-        names += ["model.23.proto.cv3"] + [f"model.23.cv4.{l}.2" for l in range(3)]
+        names += ["model.23.proto.cv3"]
+        if dense or not (mode & 2):
+            names += [f"model.23.cv4.{l}.2" for l in range(3)]
     for n in names:
         got = eng.read_tensor(eng.find_tensor(n))
         truth = nchw_to_nhwc(t32[n])
@@ -280,11 +293,78 @@ def test_end_to_end_bf16_accuracy(variant, seg, shape):
         e_emu = float((nchw_to_nhwc(t16[n]) - truth).abs().mean())
         rep[n] = (e_eng, e_emu)
         assert e_eng <= 1.25 * e_emu + 1e-6, (n, e_eng, e_emu)
+    if not dense:
+        # the winners' rows against the oracle's maps at the same anchors (all three levels pooled: a level may hold a handful of winners)
+        A_l = [(shape[1] // s) * (shape[2] // s) for s in (8, 16, 32)]
+        k = min(eng.max_det, sum(A_l))
+        for bit, pre, width, got_rows in ((1, "model.23.one2one_cv2", 64, rows), (2, "model.23.cv4", 32, cfrows)):
+            if not (mode & bit):
+                continue
+            flat32 = torch.cat([nchw_to_nhwc(t32[f"{pre}.{l}.2"]).reshape(B, -1, width) for l in range(3)], 1)
+            flat16 = torch.cat([nchw_to_nhwc(t16[f"{pre}.{l}.2"]).reshape(B, -1, width) for l in range(3)], 1)
+            bi = torch.arange(B)[:, None].expand(B, k)
+            truth, emu = flat32[bi, sel[:, :k].long()], flat16[bi, sel[:, :k].long()]
+            e_eng, e_emu = float((got_rows[:, :k] - truth).abs().mean()), float((emu - truth).abs().mean())
+            rep[pre + " (winners)"] = (e_eng, e_emu)
+            assert e_eng <= 1.25 * e_emu + 1e-6, (pre, e_eng, e_emu)
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, f"e2e_bf16_{variant}.json"), "w") as f:
         json.dump(rep, f, indent=1)
     print(variant, shape, {k: (round(a, 5), round(b, 5)) for k, (a, b) in rep.items()})
     eng.close()
+
+
+@pytest.mark.parametrize("variant,seg,shape", [("s", True, (3, 160, 192)), ("n", False, (2, 256, 384)), ("s", False, (1, 480, 608)), ("m", True, (1, 96, 128))])
+def test_winners_only_head_equals_dense(variant, seg, shape, monkeypatch):
+    """The default head evaluates the box branch (and the coefficient branch where its width is 32) at the top-k winners only
+    (head_branch.hip). Against the same engine with every branch dense (YOLOP_DENSE_HEAD=1): anchors, classes and scores are bit-identical
+    (they depend on the class branch alone); the winners' box logits / coefficients are the dense maps' values at those anchors up to fp32
+    summation order through two bf16-rounded intermediates - almost all of them within 1e-3 of the map's range, none beyond 5 %; boxes
+    move by a fraction of a pixel. Frame borders (zero padding of both 3x3 convolutions) are part of every case: winners sit on them."""
+    st, im = make_case(variant, 80, seg, 0, shape)
+    imc = im.cuda()
+    B = shape[0]
+    sp = _engine(variant, 80, seg, "bf16", st)
+    sp.set_autotune(False)
+    out_s = {k: v.cpu() for k, v in sp.forward(imc).items() if v is not None}
+    mode, sel, rows, cfrows = sp.head_winners(B)
+    assert mode & 1, "the box branch should run winners-only for this model"
+    sp.close()
+    monkeypatch.setenv("YOLOP_DENSE_HEAD", "1")
+    de = _engine(variant, 80, seg, "bf16", st)
+    de.set_autotune(False)
+    out_d = {k: v.cpu() for k, v in de.forward(imc).items() if v is not None}
+    assert de.head_winners(B)[0] == 0
+    assert torch.equal(out_s["idx"], out_d["idx"]) and torch.equal(out_s["det"][..., 4:], out_d["det"][..., 4:])
+    A_l = [(shape[1] // s) * (shape[2] // s) for s in (8, 16, 32)]
+    k = min(sp.max_det, sum(A_l))
+    bi = torch.arange(B)[:, None].expand(B, k)
+    for bit, pre, width, got_rows in ((1, "model.23.one2one_cv2", 64, rows), (2, "model.23.cv4", 32, cfrows)):
+        if not (mode & bit):
+            continue
+        dense = torch.cat([de.read_tensor(de.find_tensor(f"{pre}.{l}.2")).reshape(B, -1, width) for l in range(3)], 1)
+        want = dense[bi, sel[:, :k].long()]
+        d = (got_rows[:, :k] - want).abs()
+        rng = float(want.abs().max())
+        print(pre, "winners vs dense: max", float(d.max()), "of range", rng, "; fraction beyond 1e-3 of the range", float((d > 1e-3 * rng).float().mean()))
+        assert float(d.max()) <= 0.05 * rng and float((d > 1e-3 * rng).float().mean()) < 0.02
+    on_border = 0
+    for b in range(B):
+        for a in sel[b, :k].tolist():
+            off = 0
+            for l, s in enumerate((8, 16, 32)):
+                h, w = shape[1] // s, shape[2] // s
+                if a < off + h * w:
+                    y, x = divmod(a - off, w)
+                    on_border += int(y in (0, h - 1) or x in (0, w - 1))
+                    break
+                off += h * w
+    print("winners on a frame border:", on_border)
+    assert on_border > 0 or shape[1] > 256          # (the small maps always put winners on the border; a 60x76 P3 map need not)
+    assert float((out_s["det"][..., :4] - out_d["det"][..., :4]).abs().max()) < 2.0       # (px; a 0.2 % logit difference on a stride-32 winner is 0.6 px)
+    if seg:
+        assert float((out_s["coeff"] - out_d["coeff"]).abs().max()) <= 0.05 * float(out_d["coeff"].abs().max()) + 1e-6
+    de.close()
 
 
 def test_topk_adversarial():

@@ -19,3 +19,9 @@ for i, n in enumerate(names):
     print(f"{n:16s} {(t[i + 1] - t[i]) / 100.0:8.2f} us")
 print(f"{'total':16s} {(t[6] - t[0]) / 100.0:8.2f} us")
 print(f"stage-2 rounds {t[7] >> 32}, candidates in the last round's select {t[7] & 0xffffffff}")
+buf = (C.c_uint64 * 8)()
+lib.yp_debug_head_branch_clocks(buf)
+t = [int(x) for x in buf]
+names = ["position list", "plane 0", "channel chunks", "store"]
+print(f"position kernel, workgroup 0's first tile (level {t[5] >> 32}, {t[5] & 0xffffffff} chunks): " + ", ".join(f"{n} {(t[i + 1] - t[i]) / 100.0:.2f}" for i, n in enumerate(names))
+      + f" | total {(t[4] - t[0]) / 100.0:.2f} us; launch: {t[6]} tiles, {t[7]} positions")

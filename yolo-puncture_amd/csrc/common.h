@@ -90,6 +90,8 @@ struct Op {
     bool fused6 = false;          // plan decision: dw -> pw -> this 1x1 (+ the class-max keys) run as conv_dwpw_kernel's TAIL form
     int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
     bool nms = false;             // OP_HEAD: conf filter + class-aware NMS (YOLOv8 / YOLO11) instead of the two-stage top-k (v10)
+    int hb_box[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}}, hb_cf[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};   // OP_HEAD (v10): op indices of the box / coefficient branch convs per level ({0,1,2} = 3x3, 3x3, 1x1), -1 = none
+    bool sparse_box = false, sparse_cf = false;   // plan decision: that branch runs on the stage-1 winners only (head_branch.hip); its dense ops are skipped
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -211,7 +213,36 @@ struct HeadParams {
     // NMS heads (YOLOv8 / YOLO11, head_nms.hip): device parameters [conf, iou] and per-image candidate scratch [B][A][8] floats
     const float* nms_params;
     float* nms_ws;
+    // winners-only head (round 3): stage 1 leaves its winners in sp_sel / sp_wlist / sp_wcount / sp_thr, the branch kernel(s) fill
+    // sp_box [B][max_det][64] (and sp_cf [B][max_det][32]), stage 2 + decode read those rows by rank instead of box[] / cf[]
+    int* sp_sel; int* sp_wlist; int* sp_wcount; unsigned* sp_thr; float* sp_box; float* sp_cf;
+    int* sp_plist; int* sp_pcount; int sp_plist_off[3], sp_plist_cap[3];   // needed positions per level (see HeadBranchParams); null = not wanted
 };
+hipError_t launch_head_stage1(const HeadParams& p, hipStream_t st);
+hipError_t launch_head_stage2(const HeadParams& p, hipStream_t st);
+constexpr int HEAD_MAXK = 512;
+// The box / mask-coefficient branch of the v10 one-to-one head evaluated at the stage-1 winners only (head_branch.hip)
+struct HeadBranchParams {
+    const void* x[3]; int x_stride[3], x_coff[3], H[3], W[3], Cin[3]; size_t x_bytes[3];     // the levels' feature maps (bf16 NHWC views)
+    const void* w0[3]; int Kpad0[3]; const float* b0[3];                                       // 3x3 Cin -> cmid, packed [cmid^][9*Cin]
+    const void* w1[3]; int Kpad1[3]; const float* b1[3];                                       // 3x3 cmid -> cmid
+    const void* w2[3]; int Kpad2[3]; const float* b2[3];                                       // 1x1 cmid -> cout, no activation
+    int act0, act1;
+    int B, max_det, maxk, cmid, cout;
+    int A0, A1;                                   // anchors of level 0 / 1 (anchor id -> level-local pixel)
+    const int* sel;                               // [B][maxk] stage-1 winners (anchor ids, rank order)
+    const int* wlist;                             // [B][3][maxk] ranks of the winners that lie on a level
+    const int* wcount;                            // [B][3]
+    float* out;                                   // [B][max_det][cout] fp32 rows by rank
+    // positions form (head_pos_kernel + head_win_kernel): the first 3x3 once per NEEDED position (the union of the winners' in-frame 3x3
+    // neighbourhoods, listed by the stage-1 kernel), its output in a position-addressed map that the winners' second 3x3 gathers from
+    const int* plist; const int* pcount;          // per level: entries image << 20 | level-local pixel; pcount[3]
+    int plist_off[3], plist_cap[3];               // level l's list = plist + plist_off[l], at most plist_cap[l] entries
+    void* t0; size_t t0_off[3], t0_bytes;         // bf16 [level][B][H_l*W_l][cmid]: element offset of level l
+    int pos_grid;                                 // workgroups of the (persistent) position kernel
+};
+bool head_branch_valid(const HeadBranchParams& p);
+hipError_t launch_head_branch(const HeadBranchParams& p, hipStream_t st);
 hipError_t launch_head_nms(const HeadParams& p, hipStream_t st);
 size_t head_nms_scratch_bytes(int B, int A);
 
@@ -320,6 +351,7 @@ hipError_t launch_letterbox(const uint8_t* src, int h0, int w0, uint8_t* dst, in
                             int left, int pad, hipStream_t st);
 size_t head_scratch_bytes(int B, int A);
 hipError_t head_read_clocks(unsigned long long* out8);
+hipError_t head_branch_read_clocks(unsigned long long* out8);
 hipError_t launch_copy_out(const float* det, float* det_out, const int32_t* idx, int32_t* idx_out, const float* coeff, float* coeff_out,
                            size_t rows, hipStream_t st);
 hipError_t launch_anchor_max_level(const float* cls, int B, int HW, int nc, unsigned* out, hipStream_t st);

@@ -12,6 +12,9 @@
 // 8 waves as WGM (pixel groups) x WGN (32 output channels each), WGM * WGN = 8; a wave holds up to FMX pixel fragments x 2
 // channel fragments.
 #include "common.h"
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 
 namespace yp {
 
@@ -30,8 +33,16 @@ constexpr int T1_NS = 3;         // weight ring slots; a stage is one tap ROW (3
 
 struct Tile1Geo { int TR, TC, tiles_h, tiles_w, nfr, ppc; };   // ppc: 16-pixel pieces per chunk plane of the patch
 
-template <int WGN, bool HAS_RES, bool OUT_F32>
+// debug (YOLOP_T1_CLOCKS=1, the <4,false,false> instantiation only): 100-MHz stamps of workgroup 0's waves - [0] start, [1] patch plane 0 and the
+// first weight stages landed (first barrier passed), [2] main loop done, [3] epilogue stores issued
+__device__ unsigned long long g_t1_clk[8][4];
+__device__ int g_t1_abl;      // timing ablations of the stamped instantiation (YOLOP_T1_ABL, results become wrong): 1 no weight pieces in the loop, 2 no MFMAs, 4 no fragment reads
+
+template <int WGN, bool HAS_RES, bool OUT_F32, bool CLK = false>
 __global__ __launch_bounds__(512) void conv_tile1_kernel(const ConvParams p, const Tile1Geo g) {
+#define T1_STAMP(i) do { if (CLK && blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_t1_clk[threadIdx.x >> 6][i] = wall_clock64(); } while (0)
+    T1_STAMP(0);
+    const int abl = CLK ? g_t1_abl : 0;
     constexpr int NW = 8, WGM = NW / WGN, FN = 2;
     constexpr int BN = WGN * FN * 16;
     constexpr int WP = BN * 64 / 1024;                 // weight pieces per k-step
@@ -102,6 +113,7 @@ __global__ __launch_bounds__(512) void conv_tile1_kernel(const ConvParams p, con
     auto issue_piece = [&](int j, int stage) {
         const int ch = stage / 3, ky = stage - ch * 3;
         if (!wlive[j]) return;                                               // (wave-uniform; an out-of-range piece would zero-fill LDS)
+        if (CLK && (abl & 1) && stage >= T1_NS - 1) return;
         const unsigned voff = (stage < nst) ? wbase[j] + (unsigned)((ky * 3 * p.Cin + ch * 32) * 2) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(Ws + (stage % T1_NS) * SW + (wave + j * NW) * 1024), 16, voff, 0, 0, 0);
     };
@@ -148,40 +160,69 @@ __global__ __launch_bounds__(512) void conv_tile1_kernel(const ConvParams p, con
     if (full) wait_vt1<(T1_NS - 1) * LPW>();         // the patch has landed (only the ring's weight pieces may still be in flight)
     else wait_vt1<(T1_NS - 1) * (LPW - 1)>();
     __builtin_amdgcn_s_barrier();
+    T1_STAMP(1);
 
-    for (int st = 0; st < nst; ++st) {
-        if (full) wait_vt1<(T1_NS - 2) * LPW>();     // this wave's pieces of stage st have landed
+    // Main loop, software-pipelined by one tap: the nine fragment reads of tap t+1 are issued BEFORE the 14 MFMAs of tap t, into a second
+    // register set. (Left to the compiler, a pair of MFMAs followed each fragment read at a distance of one or two reads: every pair
+    // waited out its own LDS round trip, and with both waves of a SIMD in the same phase behind the stage barrier the stage took the SUM of
+    // its LDS time and its MFMA time - 2900 cycles for 1728 + 1344; in-kernel stamps: main loop 15.9 us of a 20-us workgroup.) The pixel
+    // fragments of the next STAGE's first tap are prefetched across the barrier as well (the patch is resident; a chunk plane lands two
+    // stages before its first use); its weight fragments are in the ring slot the barrier releases and are read right behind it.
+    bf16x8 xf[2][T1_FMX], wf[2][FN];
+    auto read_x = [&](bf16x8 (&dst)[T1_FMX], int stage, int kx) {
+        const int ch = stage / 3, ky = stage - ch * 3;
+        const unsigned char* xs = Xs + (size_t)ch * g.ppc * 1024;
+        const unsigned tapb = (unsigned)((ky * HC + kx) * 64);
+        if (CLK && (abl & 4)) return;
+#pragma unroll
+        for (int f = 0; f < T1_FMX; ++f) {
+            const unsigned L = lbase[f] + tapb;
+            dst[f] = *(const bf16x8*)(xs + (L ^ ((L >> 3) & 32u)));
+        }
+    };
+    auto read_w = [&](bf16x8 (&dst)[FN], int stage, int kx) {
+        const unsigned char* ws = Ws + (stage % T1_NS) * SW;
+        if (CLK && (abl & 4)) return;
+#pragma unroll
+        for (int a = 0; a < FN; ++a) dst[a] = *(const bf16x8*)(ws + wl[kx][a]);
+    };
+    auto stage = [&](int st, auto Pc) {
+        constexpr int P = decltype(Pc)::value;           // register set that holds this stage's first tap
+        if (full) wait_vt1<(T1_NS - 2) * LPW>();         // this wave's pieces of stage st have landed
         else wait_vt1<(T1_NS - 2) * (LPW - 1)>();
         __builtin_amdgcn_s_barrier();
         const int ch = st / 3, ky = st - ch * 3;
         if (ky == 0 && ch + 1 < nchunk) issue_x(ch + 1);
-        const unsigned char* ws = Ws + (st % T1_NS) * SW;
-        const unsigned char* xs = Xs + (size_t)ch * g.ppc * 1024;
+        read_w(wf[P], st, 0);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-            const unsigned tapb = (unsigned)((ky * HC + kx) * 64);
-            bf16x8 wf[FN], xf[T1_FMX];
+            constexpr int dummy = 0; (void)dummy;
+            const int cur = (P + kx) & 1, nxt = cur ^ 1;
+            if (kx < 2) { read_w(wf[nxt], st, kx + 1); read_x(xf[nxt], st, kx + 1); }
+            else if (st + 1 < nst) read_x(xf[nxt], st + 1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(CLK && (abl & 2))) {
 #pragma unroll
-            for (int a = 0; a < FN; ++a) wf[a] = *(const bf16x8*)(ws + wl[kx][a]);
-            // straight-line: every fragment read is issued before the first MFMA waits for one. Fragments beyond the wave's share
-            // recompute a valid pixel and are never stored.
+                for (int f = 0; f < T1_FMX; ++f)
 #pragma unroll
-            for (int f = 0; f < T1_FMX; ++f) {
-                const unsigned L = lbase[f] + tapb;
-                xf[f] = *(const bf16x8*)(xs + (L ^ ((L >> 3) & 32u)));
+                    for (int a = 0; a < FN; ++a) acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][a], xf[cur][f], acc[a][f], 0, 0, 0);
             }
-#pragma unroll
-            for (int f = 0; f < T1_FMX; ++f)
-#pragma unroll
-                for (int a = 0; a < FN; ++a) acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[f], acc[a][f], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             // one piece of stage st + NS - 1 behind each tap's MFMAs: the ~300-cycle issue stall runs under their execution; the
             // slot it overwrites (stage st - 1) was finished with before this stage's barrier
             if (kx < LPW) issue_piece(kx, it);
         }
         ++it;
+    };
+    read_x(xf[0], 0, 0);
+    for (int st = 0; st + 1 < nst; st += 2) {
+        stage(st, std::integral_constant<int, 0>{});
+        stage(st + 1, std::integral_constant<int, 1>{});
     }
+    if (nst & 1) stage(nst - 1, std::integral_constant<int, 0>{});
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+    T1_STAMP(2);
 #pragma unroll
     for (int f = 0; f < T1_FMX; ++f) {
         if (f >= myf) continue;
@@ -211,6 +252,8 @@ __global__ __launch_bounds__(512) void conv_tile1_kernel(const ConvParams p, con
             }
         }
     }
+    T1_STAMP(3);
+#undef T1_STAMP
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -271,6 +314,25 @@ static hipError_t launch_tile1_var(const ConvParams& p, hipStream_t st) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
         if (e != hipSuccess) return e;
         attr = true;
+    }
+    if constexpr (WGN == 4 && !HAS_RES && !OUT_F32) {
+        static const bool clocks = [] { const char* v = std::getenv("YOLOP_T1_CLOCKS"); return v && *v == '1'; }();
+        if (clocks) {
+            auto kc = conv_tile1_kernel<4, false, false, true>;
+            { const char* v = std::getenv("YOLOP_T1_ABL"); const int ab = v ? atoi(v) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_t1_abl), &ab, sizeof(int)); }
+            static bool attr_c = false;
+            if (!attr_c) { (void)hipFuncSetAttribute((const void*)kc, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)); attr_c = true; }
+            hipLaunchKernelGGL(kc, dim3(tiles), dim3(512), sh, st, p, g);
+            hipError_t e = hipStreamSynchronize(st);
+            if (e != hipSuccess) return e;
+            unsigned long long h[8][4];
+            (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_t1_clk), sizeof(h));
+            double ph[3] = {0, 0, 0};
+            for (int w = 0; w < 8; ++w) for (int i = 0; i < 3; ++i) ph[i] += (double)(h[w][i + 1] - h[w][i]) / 100.0 / 8.0;
+            fprintf(stderr, "[tile1 clocks] Cin %d Cout %d %dx%d tiles %d (TR %d TC %d): fill %.2f us, main loop %.2f us, epilogue %.2f us (workgroup 0, mean of 8 waves)\n",
+                    p.Cin, p.Cout, p.Ho, p.Wo, tiles, g.TR, g.TC, ph[0], ph[1], ph[2]);
+            return hipSuccess;
+        }
     }
     hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), sh, st, p, g);
     return hipGetLastError();

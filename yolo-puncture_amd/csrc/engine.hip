@@ -63,10 +63,13 @@ struct yp_engine {
     std::map<std::array<int, 3>, bool> auto_replay;
     bool fuse = true;             // dw->pw fusion (YOLOP_NO_FUSE=1 disables, for A/B)
     bool tail = false;            // conv_dwpw TAIL form (YOLOP_TAIL=1 at yp_create enables; see make_plan)
+    bool sparse_head = true;      // v10 head: box / coefficient branches on the stage-1 winners only (YOLOP_DENSE_HEAD=1 at yp_create disables)
+    void* sp_ws = nullptr; size_t sp_ws_bytes = 0;   // winners-only head: sel / wlist / wcount / thr / box rows / coefficient rows
     bool tune = true;             // plan-time autotuning of the conv tile configuration
     hipStream_t own_stream = nullptr;
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
     hipGraphExec_t gexec = nullptr;
+    hipGraph_t gsrc = nullptr;                       // the captured graph gexec was instantiated from: kept alive as long as the executable (see drop_graph)
     std::vector<hipStream_t> lane_streams;   // [0] unused (lane 0 = own_stream)
     std::vector<hipEvent_t> lane_events;     // [op] "op done" ; [n + lane] join of a side lane ; [n + nl + lane] fork into a side lane
     bool use_lanes = true;
@@ -535,6 +538,7 @@ static int build_graph(yp_engine& e) {
         B.conv(pb + ".0", x, B.full(b0), 3, 1, ACT_SILU);
         B.conv(pb + ".1", B.full(b0), B.full(b1), 3, 1, ACT_SILU);
         B.conv(pb + ".2", B.full(b1), B.full(b2), 1, 1, ACT_NONE);
+        for (int j = 0; j < 3; ++j) { head.hb_box[l][j] = (int)e.ops.size() - 3 + j; head.hb_cf[l][j] = -1; }
         const int k0 = B.tensor(pc + ".0.0", x.C, sd), k1 = B.tensor(pc + ".0.1", hc3, sd), k2 = B.tensor(pc + ".1.0", hc3, sd),
                   k3 = B.tensor(pc + ".1.1", hc3, sd), k4 = B.tensor(pc + ".2", nc, sd, true);
         B.lane = 2 + 3 * l;                                           // class branch
@@ -560,6 +564,7 @@ static int build_graph(yp_engine& e) {
             B.conv(pm + ".0", x, B.full(m0), 3, 1, ACT_SILU);
             B.conv(pm + ".1", B.full(m0), B.full(m1), 3, 1, ACT_SILU);
             B.conv(pm + ".2", B.full(m1), B.full(m2), 1, 1, ACT_NONE);
+            for (int j = 0; j < 3; ++j) head.hb_cf[l][j] = (int)e.ops.size() - 3 + j;
             head.cf[l] = B.full(m2);
         }
     }
@@ -663,11 +668,81 @@ static int finish_graph_passes(yp_engine& e) {
 // plan: resolve shapes for (B,H,W), compute algorithmic flops/bytes
 // ---------------------------------------------------------------------------------------------------------
 static ConvParams conv_params(const yp_engine& e, const Op& o);
+// Releases the replay executable together with the graph it was instantiated from. The source graph is NOT destroyed right after
+// hipGraphInstantiate: under ROCm 7.2 a forward that replays a re-captured multi-lane graph died with a host SIGSEGV in one full test run
+// out of three (tests/test_gpu_fullsize.py, not reproducible alone; the deterministic variant of it on the NULL stream is described at
+// forward_replay). Sharing the lifetime is a precaution against the executable referring to the source's nodes - not an established cause.
+static void drop_graph(yp_engine& e) {
+    if (e.gexec) { (void)hipGraphExecDestroy(e.gexec); e.gexec = nullptr; }
+    if (e.gsrc) { (void)hipGraphDestroy(e.gsrc); e.gsrc = nullptr; }
+}
 static DwPwParams dwpw_params(const yp_engine& e, const Op& c);
 static FrontParams front_params(const yp_engine& e, const Op& o, const uint8_t* img);
 static C2fParams c2f_params(const yp_engine& e, const Op& o);
 static ScdParams scd_params(const yp_engine& e, const Op& o);
 static size_t tensor_elem_bytes(const yp_engine& e, const TensorDesc& t) { return (t.f32 || e.dtype == DT_F32) ? 4 : 2; }
+
+// ---- winners-only head (head_branch.hip): workspace layout and parameter blocks -----------------------------------------------------------------
+struct SparseWs {
+    size_t sel, wlist, wcount, thr, box, cf, pcount, plist, t0box, t0cf, total;
+    int plist_off[3], plist_cap[3];          // per level: first entry / capacity of its position list
+    size_t t0_off[3];                        // per level: first (image, pixel) row of the position-addressed maps, in rows
+    size_t rows;                             // B * anchors
+};
+static SparseWs sparse_ws_layout(int B, int max_det, const int (&HWl)[3]) {
+    SparseWs w{};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+    w.sel = take((size_t)B * HEAD_MAXK * 4); w.wlist = take((size_t)B * 3 * HEAD_MAXK * 4); w.wcount = take((size_t)B * 3 * 4); w.thr = take((size_t)B * 4);
+    w.box = take((size_t)B * max_det * 64 * 4); w.cf = take((size_t)B * max_det * 32 * 4);
+    w.pcount = take(3 * 4);
+    size_t ents = 0, rows = 0;
+    for (int l = 0; l < 3; ++l) {
+        w.plist_off[l] = (int)ents; w.plist_cap[l] = B * std::min(HWl[l], 9 * max_det);   // a winner's 3x3 neighbourhood, never more than the level has
+        ents += (size_t)(w.plist_cap[l] + 63) & ~(size_t)63;
+        w.t0_off[l] = rows; rows += (size_t)B * HWl[l];
+    }
+    w.rows = rows;
+    w.plist = take(ents * 4);
+    w.t0box = take(rows * 64 * 2); w.t0cf = take(rows * 32 * 2);
+    w.total = off;
+    return w;
+}
+static SparseWs sparse_ws_layout(const yp_engine& e) {
+    const int hw[3] = {(e.pH / 8) * (e.pW / 8), (e.pH / 16) * (e.pW / 16), (e.pH / 32) * (e.pW / 32)};
+    return sparse_ws_layout(e.pB, e.desc.max_det, hw);
+}
+// which: 0 = box branch (one2one_cv2), 1 = mask-coefficient branch (cv4)
+static HeadBranchParams head_branch_params(const yp_engine& e, const Op& h, int which) {
+    HeadBranchParams p{};
+    const SparseWs ws = sparse_ws_layout(e);
+    char* base = (char*)e.sp_ws;
+    for (int l = 0; l < 3; ++l) {
+        const int* ids = which == 0 ? h.hb_box[l] : h.hb_cf[l];
+        if (ids[0] < 0) { p.cmid = 0; return p; }
+        const Op &c0 = e.ops[ids[0]], &c1 = e.ops[ids[1]], &c2 = e.ops[ids[2]];
+        const WeightDesc &w0 = e.weights[c0.widx], &w1 = e.weights[c1.widx], &w2 = e.weights[c2.widx];
+        const TensorDesc& ti = e.tensors[c0.in.t];
+        p.x[l] = ti.ptr; p.x_stride[l] = ti.C; p.x_coff[l] = c0.in.coff; p.H[l] = ti.H; p.W[l] = ti.W; p.Cin[l] = c0.in.C; p.x_bytes[l] = ti.bytes;
+        p.w0[l] = w0.d_w; p.Kpad0[l] = w0.Kpad; p.b0[l] = w0.d_b;
+        p.w1[l] = w1.d_w; p.Kpad1[l] = w1.Kpad; p.b1[l] = w1.d_b;
+        p.w2[l] = w2.d_w; p.Kpad2[l] = w2.Kpad; p.b2[l] = w2.d_b;
+        if (l == 0) { p.cmid = c0.out.C; p.cout = c2.out.C; p.act0 = c0.act; p.act1 = c1.act; }
+        // the shape the kernel is written for: 3x3 s1 -> 3x3 s1 -> 1x1 without activation, no residuals, equal widths on every level
+        if (c0.k != 3 || c1.k != 3 || c2.k != 1 || c0.s != 1 || c1.s != 1 || c2.s != 1 || c0.res.t >= 0 || c1.res.t >= 0 || c2.res.t >= 0 || c2.act != ACT_NONE ||
+            c0.out.C != p.cmid || c1.out.C != p.cmid || c1.in.C != p.cmid || c2.in.C != p.cmid || c2.out.C != p.cout || c0.act != p.act0 || c1.act != p.act1 ||
+            w0.cin_pad != c0.in.C || w1.cin_pad != p.cmid) { p.cmid = 0; return p; }
+    }
+    p.B = e.pB; p.max_det = e.desc.max_det; p.maxk = HEAD_MAXK;
+    p.A0 = p.H[0] * p.W[0]; p.A1 = p.H[1] * p.W[1];
+    p.sel = (const int*)(base + ws.sel); p.wlist = (const int*)(base + ws.wlist); p.wcount = (const int*)(base + ws.wcount);
+    p.out = (float*)(base + (which == 0 ? ws.box : ws.cf));
+    p.plist = (const int*)(base + ws.plist); p.pcount = (const int*)(base + ws.pcount);
+    p.t0 = base + (which == 0 ? ws.t0box : ws.t0cf); p.t0_bytes = ws.rows * (size_t)p.cmid * 2;
+    for (int l = 0; l < 3; ++l) { p.plist_off[l] = ws.plist_off[l]; p.plist_cap[l] = ws.plist_cap[l]; p.t0_off[l] = ws.t0_off[l] * (size_t)p.cmid; }
+    p.pos_grid = 256;                        // one workgroup per CU (its three plane slots fill most of a CU's LDS)
+    return p;
+}
 
 static int make_plan(yp_engine& e, int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0 || (H % 32) || (W % 32)) return fail(YP_ERR_ARG, "input must be [B,H,W,3] with H,W multiples of 32 (got %d,%d,%d)", B, H, W);
@@ -708,7 +783,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false; e.warmed = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel", "anchor_max_level_kernel"};
-    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; o.fused5 = false; o.fused6 = false; }
+    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; o.fused5 = false; o.fused6 = false; o.sparse_box = false; o.sparse_cf = false; }
     static const bool no_fold = [] { const char* v = std::getenv("YOLOP_NO_FOLD"); return v && *v == '1'; }();   // A/B switch
     for (auto& o : e.ops) {
         if (o.kind != OP_CONV || o.fold_up < 0 || e.dtype != DT_BF16 || no_fold) continue;
@@ -800,6 +875,22 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         } else if (o.kind == OP_POOL3 && e.dtype == DT_BF16 && (o.in.C & 31) == 0) o.kernel = "sppf_pool3_bf16_kernel";
         else o.kernel = (o.kind == OP_HEAD && o.nms) ? "head_nms_kernel" : kn[o.kind];
     }
+    // winners-only head (v10 top-k head, bf16): the box / coefficient branches run on the stage-1 winners inside the head op; their dense
+    // convolutions stay in the op list (yp_run_op steps them, the fp32 parity mode and YOLOP_DENSE_HEAD=1 run them) but launch nothing here
+    for (auto& o : e.ops) {
+        if (o.kind != OP_HEAD || o.nms || e.dtype != DT_BF16 || !e.sparse_head || e.desc.max_det > HEAD_MAXK || o.amax[0].t < 0) continue;
+        for (int which = 0; which < 2; ++which) {
+            const HeadBranchParams q = head_branch_params(e, o, which);
+            if (q.cmid == 0 || !head_branch_valid(q)) continue;
+            // the branch's intermediate tensors must have no reader outside the branch (they are never written in this mode)
+            (which == 0 ? o.sparse_box : o.sparse_cf) = true;
+            for (int l = 0; l < 3; ++l)
+                for (int j = 0; j < 3; ++j) {
+                    Op& c = e.ops[(which == 0 ? o.hb_box : o.hb_cf)[l][j]];
+                    c.skip = true;
+                }
+        }
+    }
     // algorithmic work of the graph as it runs: an op whose work moved into a fused consumer reports nothing and launches
     // nothing; the consumer reports the FLOPs of all its stages and the bytes of what it reads and writes (the intermediates
     // never reach HBM), a conv with a folded upsample reads the low-resolution tensor instead of its upsampled copy
@@ -831,6 +922,20 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
                 o.bytes = vb(View{o.in.t, o.in.coff, 2 * m1.in.C}) + vb(o.out) + wb(m1) + wb(m2) + wb(o);
             }
             if (o.folded) { const Op& u = e.ops[o.fold_up]; o.bytes += vb(u.in) - vb(u.out); }
+        }
+        for (auto& o : e.ops) {
+            if (o.kind != OP_HEAD) continue;
+            for (int which = 0; which < 2; ++which) {
+                if (!(which == 0 ? o.sparse_box : o.sparse_cf)) continue;
+                const HeadBranchParams q = head_branch_params(e, o, which);
+                for (int l = 0; l < 3; ++l) {        // (which level a winner lies on is data: a third each, neighbourhoods disjoint unless the level is full)
+                    const double nw = (double)B * e.desc.max_det / 3.0;
+                    const double npos = std::min(9.0 * nw, (double)B * q.H[l] * q.W[l]);
+                    o.flops += 2.0 * (npos * 9.0 * q.Cin[l] * q.cmid + nw * (9.0 * q.cmid * q.cmid + (double)q.cmid * q.cout));
+                    o.bytes += npos * (9.0 * q.Cin[l] * 2 + 2.0 * q.cmid * 2) + nw * q.cout * 4 + (9.0 * q.Cin[l] * q.cmid + 9.0 * q.cmid * q.cmid + q.cmid * q.cout) * 2;
+                }
+            }
+            if (o.sparse_box || o.sparse_cf) o.kernel = "head_select_kernel<1> + head_pos_kernel + head_win_kernel + head_select_kernel<2>";
         }
         for (auto& o : e.ops)
             if (o.skip) { o.flops = 0; o.bytes = 0; o.kernel = "-"; }
@@ -878,6 +983,18 @@ static int allocate_plan(yp_engine& e) {
             e.head_ws_bytes = need;
         }
     }
+    {
+        bool sparse = false;
+        for (const auto& o : e.ops) sparse |= o.kind == OP_HEAD && (o.sparse_box || o.sparse_cf);
+        const size_t need = sparse ? sparse_ws_layout(e).total : 0;
+        if (need > e.sp_ws_bytes) {
+            if (e.sp_ws) HIPCHK(hipFree(e.sp_ws));
+            e.sp_ws = nullptr; e.sp_ws_bytes = 0;
+            HIPCHK(hipMalloc(&e.sp_ws, need));
+            HIPCHK(hipMemset(e.sp_ws, 0, need));
+            e.sp_ws_bytes = need;
+        }
+    }
     if (e.desc.family != YP_FAMILY_V10) {
         size_t A = 0;
         for (int l = 0; l < 3; ++l) A += (size_t)(e.pH / (8 << l)) * (e.pW / (8 << l));
@@ -902,7 +1019,7 @@ static int allocate_plan(yp_engine& e) {
         HIPCHK(hipMalloc(&e.o_coeff, rows * 32 * sizeof(float)));
         e.o_cap = (size_t)e.pB;
     }
-    if (e.gexec) { (void)hipDeviceSynchronize(); (void)hipGraphExecDestroy(e.gexec); e.gexec = nullptr; }   // (never under a running replay)
+    if (e.gexec) { (void)hipDeviceSynchronize(); drop_graph(e); }   // (never under a running replay)
     e.allocated = true;
     return YP_OK;
 }
@@ -1092,6 +1209,22 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             p.det = a.det; p.idx = a.idx; p.coeff = (o.cf[0].t >= 0) ? a.coeff : nullptr; p.scratch = e.head_ws;
             for (int l = 0; l < 3; ++l) p.mk[l] = (o.amax[l].t >= 0) ? (const unsigned*)T(o.amax[l]).ptr : nullptr;
             if (o.nms) { p.nms_params = e.d_nms; p.nms_ws = (float*)e.nms_ws; return launch_head_nms(p, st); }
+            if (o.sparse_box || o.sparse_cf) {
+                // winners-only head: stage 1 -> the branch(es) on the winners -> stage 2 + decode. A branch that stays dense (an unsupported
+                // width) is read from its dense map as before.
+                const SparseWs ws = sparse_ws_layout(e);
+                char* base = (char*)e.sp_ws;
+                p.sp_sel = (int*)(base + ws.sel); p.sp_wlist = (int*)(base + ws.wlist); p.sp_wcount = (int*)(base + ws.wcount); p.sp_thr = (unsigned*)(base + ws.thr);
+                p.sp_box = o.sparse_box ? (float*)(base + ws.box) : nullptr;
+                p.sp_cf = (o.sparse_cf && p.coeff) ? (float*)(base + ws.cf) : nullptr;
+                p.sp_plist = (int*)(base + ws.plist); p.sp_pcount = (int*)(base + ws.pcount);
+                for (int l = 0; l < 3; ++l) { p.sp_plist_off[l] = ws.plist_off[l]; p.sp_plist_cap[l] = ws.plist_cap[l]; }
+                hipError_t err = launch_head_stage1(p, st);
+                if (err != hipSuccess) return err;
+                if (o.sparse_box && (err = launch_head_branch(head_branch_params(e, o, 0), st)) != hipSuccess) return err;
+                if (p.sp_cf && (err = launch_head_branch(head_branch_params(e, o, 1), st)) != hipSuccess) return err;
+                return launch_head_stage2(p, st);
+            }
             return launch_head(p, st);
         }
     }
@@ -1367,9 +1500,11 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     if (o.fused6 && o.tail_amax >= 0) wr.push_back(e.ops[o.tail_amax].out);
     if (o.kind == OP_HEAD)
         for (int l = 0; l < 3; ++l) {
-            if (o.box[l].t >= 0) rd.push_back(o.box[l]);
+            if (o.sparse_box) rd.push_back(e.ops[o.hb_box[l][0]].in);              // the level's feature map instead of the dense box map
+            else if (o.box[l].t >= 0) rd.push_back(o.box[l]);
             if (o.cls[l].t >= 0) rd.push_back(o.cls[l]);
-            if (o.cf[l].t >= 0) rd.push_back(o.cf[l]);
+            if (o.sparse_cf) rd.push_back(e.ops[o.hb_cf[l][0]].in);
+            else if (o.cf[l].t >= 0) rd.push_back(o.cf[l]);
             if (o.amax[l].t >= 0) rd.push_back(o.amax[l]);
         }
 }
@@ -1643,6 +1778,7 @@ int yp_create(const yp_model_desc* desc, int device, yp_engine** out) {
     e->desc = *desc; e->device = device; e->dtype = desc->dtype;
     { const char* nf = std::getenv("YOLOP_NO_FUSE"); e->fuse = !(nf && *nf == '1'); }
     { const char* tf = std::getenv("YOLOP_TAIL"); e->tail = tf && *tf == '1'; }
+    { const char* dh = std::getenv("YOLOP_DENSE_HEAD"); e->sparse_head = !(dh && *dh == '1'); }
     int rc = build_graph(*e);
     if (rc != YP_OK) return rc;
     for (const Op& o : e->ops)
@@ -1662,8 +1798,9 @@ int yp_destroy(yp_engine* e) {
     if (e->head_ws) (void)hipFree(e->head_ws);
     if (e->nms_ws) (void)hipFree(e->nms_ws);
     if (e->d_nms) (void)hipFree(e->d_nms);
+    if (e->sp_ws) (void)hipFree(e->sp_ws);
     if (e->o_det) { (void)hipFree(e->o_det); (void)hipFree(e->o_idx); (void)hipFree(e->o_coeff); }
-    if (e->gexec) (void)hipGraphExecDestroy(e->gexec);
+    drop_graph(*e);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
     if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
@@ -1933,8 +2070,7 @@ static int forward_replay(yp_engine* e, const uint8_t* in_dev, int B, int H, int
         if (e->gexec) {
             // the previous executable may still be running (replays are asynchronous): never destroy it under the GPU
             if (e->ev_done) HIPCHK(hipEventSynchronize(e->ev_done));
-            (void)hipGraphExecDestroy(e->gexec);
-            e->gexec = nullptr;
+            drop_graph(*e);
         }
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
@@ -1942,8 +2078,8 @@ static int forward_replay(yp_engine* e, const uint8_t* in_dev, int B, int H, int
         hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
         if (rc != YP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (ce != hipSuccess) return fail(YP_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
+        e->gsrc = g;
         HIPCHK(hipGraphInstantiate(&e->gexec, g, nullptr, nullptr, 0));
-        (void)hipGraphDestroy(g);
         e->gkey.B = B; e->gkey.H = H; e->gkey.W = W; e->gkey.in = in_dev; e->gkey.det = ag.det; e->gkey.idx = ag.idx; e->gkey.coeff = ag.coeff;
     }
     hipStream_t rs = st;
@@ -2025,6 +2161,29 @@ int yp_debug_head_clocks(uint64_t* out8) {
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(head_read_clocks((unsigned long long*)out8));
     return YP_OK;
+}
+
+int yp_debug_head_branch_clocks(uint64_t* out8) {
+    if (!out8) return fail(YP_ERR_ARG, "yp_debug_head_branch_clocks: null output");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(head_branch_read_clocks((unsigned long long*)out8));
+    return YP_OK;
+}
+
+int yp_debug_head_winners(yp_engine* e, int32_t* sel_host, float* box_host, float* coeff_host) {
+    if (!e) return fail(YP_ERR_ARG, "null engine");
+    if (!e->allocated) return fail(YP_ERR_STATE, "no forward has run yet");
+    const Op* h = nullptr;
+    for (const Op& o : e->ops) if (o.kind == OP_HEAD) h = &o;
+    if (!h || !(h->sparse_box || h->sparse_cf) || !e->sp_ws) return 0;           // dense head: nothing to show
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    const SparseWs ws = sparse_ws_layout(*e);
+    const char* base = (const char*)e->sp_ws;
+    if (sel_host) HIPCHK(hipMemcpy(sel_host, base + ws.sel, (size_t)e->pB * HEAD_MAXK * 4, hipMemcpyDeviceToHost));
+    if (box_host && h->sparse_box) HIPCHK(hipMemcpy(box_host, base + ws.box, (size_t)e->pB * e->desc.max_det * 64 * 4, hipMemcpyDeviceToHost));
+    if (coeff_host && h->sparse_cf) HIPCHK(hipMemcpy(coeff_host, base + ws.cf, (size_t)e->pB * e->desc.max_det * 32 * 4, hipMemcpyDeviceToHost));
+    return (h->sparse_box ? 1 : 0) | (h->sparse_cf ? 2 : 0);
 }
 
 int yp_debug_contour_clocks(uint64_t* out12) {
@@ -2153,8 +2312,7 @@ int yp_set_graph(yp_engine* e, int enable) {
         // caller that alternates one-frame calls (eager) with batches (replay) pays neither a sync nor a re-capture
         HIPCHK(hipSetDevice(e->device));
         if (e->ev_done) HIPCHK(hipEventSynchronize(e->ev_done));
-        (void)hipGraphExecDestroy(e->gexec);
-        e->gexec = nullptr;
+        drop_graph(*e);
         e->auto_replay.clear();
     }
     e->use_graph = enable != 0;

@@ -248,6 +248,11 @@ __device__ __forceinline__ unsigned wave_append(bool have, unsigned* counter) {
     return base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// MODE 0: stage 1 + stage 2 + decode from the dense box / coefficient maps (one launch).
+// MODE 1: stage 1 only - the winners go to global memory (anchor ids in rank order, per-level rank lists for head_branch.hip, the
+//         stage-1 threshold); MODE 2: stage 2 + decode, reading the winners back and the box / coefficient rows the branch kernel made for
+//         them (p.sp_box / p.sp_cf, indexed by rank) - the "winners-only" head.
+template <int MODE>
 __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, const unsigned* __restrict__ mkey) {
     extern __shared__ __attribute__((aligned(16))) unsigned long long lds[];
     unsigned long long* keys = lds;                 // [CAP]
@@ -274,6 +279,8 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
 
     HEAD_STAMP(0);
     if (blockIdx.x == 0 && tid == 0) g_head_clk[7] = 0ull;
+    unsigned thr_bits = 0u;
+    if constexpr (MODE != 2) {
     // ---- stage 1: top-k anchors by (max score desc, anchor asc) ---------------------------------------------------------
     // Every thread keeps its <= CAP / HT keys in registers (anchor a = tid + i * HT: all loads in flight at once). The k-th largest of the
     // HT per-thread maxima is a LOWER bound T0 of the k-th largest key (k threads hold a key >= it), so the exact select only has to
@@ -316,6 +323,74 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
     __syncthreads();
     select_topk_sorted(keys, (int)nfill, k, best, tmp, S, (unsigned)A);
     HEAD_STAMP(3);
+    thr_bits = (unsigned)(best[k - 1] >> 32);   // every selected anchor has a class with score >= this
+    if constexpr (MODE == 1) {
+        // hand the winners over: anchor ids by rank, and per level the ranks that lie on it (order inside a level's list is irrelevant)
+        __shared__ unsigned s_wc[3], s_pc[3], s_pb[3];
+        unsigned* const bits = (unsigned*)keys;                         // (the select is done with `keys`) one bit per anchor, levels word-aligned
+        const int hw0 = locate.A0, hw1 = locate.A1, hw2 = locate.A2;
+        const int wb1 = (hw0 + 31) >> 5, wb2 = wb1 + ((hw1 + 31) >> 5), nwt = wb2 + ((hw2 + 31) >> 5);
+        if (tid < 3) { s_wc[tid] = 0u; s_pc[tid] = 0u; }
+        if (p.sp_plist) for (int i = tid; i < nwt; i += HT) bits[i] = 0u;
+        __syncthreads();
+        for (int r = tid; r < k; r += HT) {
+            const int a = (int)(0xFFFFFFFFu - (unsigned)(best[r] & 0xFFFFFFFFull));
+            p.sp_sel[(size_t)b * HEAD_MAXK + r] = a;
+            int l, loc, HWl;
+            locate(a, l, loc, HWl);
+            p.sp_wlist[((size_t)b * 3 + l) * HEAD_MAXK + atomicAdd(&s_wc[l], 1u)] = r | (loc << 9);     // rank (< 512) and level-local pixel in one word
+            if (p.sp_plist) {
+                // the positions whose first-convolution outputs this winner's second 3x3 reads: its in-frame 3x3 neighbourhood
+                const int Wl = l == 0 ? w0 : l == 1 ? w1 : w2, Hl = HWl / Wl, wbl = l == 0 ? 0 : l == 1 ? wb1 : wb2;
+                const int y = loc / Wl, x = loc - y * Wl;
+                for (int dy = -1; dy <= 1; ++dy)
+                    for (int dx = -1; dx <= 1; ++dx) {
+                        const int yy = y + dy, xx = x + dx;
+                        if ((unsigned)yy < (unsigned)Hl && (unsigned)xx < (unsigned)Wl) {
+                            const int n = yy * Wl + xx;
+                            atomicOr(&bits[wbl + (n >> 5)], 1u << (n & 31));
+                        }
+                    }
+            }
+        }
+        __syncthreads();
+        if (tid < 3) p.sp_wcount[b * 3 + tid] = (int)s_wc[tid];
+        if (tid == 0) p.sp_thr[b] = thr_bits;
+        if (p.sp_plist) {
+            // distinct positions per level -> this image's share of the level's list (all images append to one list per level)
+            for (int i = tid; i < nwt; i += HT) {
+                const unsigned w = bits[i];
+                if (w) atomicAdd(&s_pc[i >= wb2 ? 2 : i >= wb1 ? 1 : 0], (unsigned)__popc(w));
+            }
+            __syncthreads();
+            if (tid < 3) { s_pb[tid] = (unsigned)atomicAdd(&p.sp_pcount[tid], (int)s_pc[tid]); s_pc[tid] = 0u; }
+            __syncthreads();
+            const int off0 = p.sp_plist_off[0], off1 = p.sp_plist_off[1], off2 = p.sp_plist_off[2];
+            const int cap0 = p.sp_plist_cap[0], cap1 = p.sp_plist_cap[1], cap2 = p.sp_plist_cap[2];
+            for (int i = tid; i < nwt; i += HT) {
+                unsigned w = bits[i];
+                if (!w) continue;
+                const int l = i >= wb2 ? 2 : i >= wb1 ? 1 : 0;
+                unsigned at = s_pb[l] + atomicAdd(&s_pc[l], (unsigned)__popc(w));
+                const int wbl = l == 0 ? 0 : l == 1 ? wb1 : wb2, off = l == 0 ? off0 : l == 1 ? off1 : off2, cap = l == 0 ? cap0 : l == 1 ? cap1 : cap2;
+                while (w) {
+                    const int bit = __ffs((int)w) - 1;
+                    w &= w - 1u;
+                    if ((int)at < cap) p.sp_plist[off + at] = (b << 20) | (((i - wbl) << 5) + bit);
+                    ++at;
+                }
+            }
+        }
+        HEAD_STAMP(6);
+        return;
+    }
+    }   // MODE != 2
+    else {
+        thr_bits = p.sp_thr[b];
+        for (int r = tid; r < k; r += HT) best[r] = ((unsigned long long)0u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p.sp_sel[(size_t)b * HEAD_MAXK + r]);
+        __syncthreads();
+        HEAD_STAMP(1); HEAD_STAMP(2); HEAD_STAMP(3);
+    }
     for (int r = tid; r < k; r += HT) {
         const int a = (int)(0xFFFFFFFFu - (unsigned)(best[r] & 0xFFFFFFFFull));
         sel[r] = a;
@@ -323,7 +398,6 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
         locate(a, l, loc, HWl);
         selrow[r] = (gfptr)((l == 0 ? cls0 : l == 1 ? cls1 : cls2) + ((size_t)b * HWl + loc) * p.nc);   // class-logit row of the r-th selected anchor
     }
-    const unsigned thr_bits = (unsigned)(best[k - 1] >> 32);   // every selected anchor has a class with score >= this
     __syncthreads();
 
     // ---- stage 2: top-k of the k*nc (rank, class) candidates. A candidate below the stage-1 threshold can never be
@@ -445,16 +519,18 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
         const int r = r0 + (tid >> 2), sd = tid & 3;
         const bool live = r < p.max_det && r < have;
         float dist = 0.f, score = 0.f;
-        int a = -1, cls = 0, l = 0, loc = 0, HWl = 1;
+        int a = -1, cls = 0, l = 0, loc = 0, HWl = 1, srow = 0;
         if (live) {
             const unsigned long long key = carry[r];
             score = __uint_as_float((unsigned)(key >> 32));
             const int f = (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull));
             const int row = f / p.nc;
+            srow = row;
             cls = f - row * p.nc;
             a = sel[row];
             locate(a, l, loc, HWl);
-            const float4* bp = (const float4*)((l == 0 ? box0 : l == 1 ? box1 : box2) + ((size_t)b * HWl + loc) * 64 + sd * 16);
+            const float4* bp = MODE == 2 ? (const float4*)(p.sp_box + ((size_t)b * p.max_det + row) * 64 + sd * 16)
+                                         : (const float4*)((l == 0 ? box0 : l == 1 ? box1 : box2) + ((size_t)b * HWl + loc) * 64 + sd * 16);
             const float4 q0 = bp[0], q1 = bp[1], q2 = bp[2], q3 = bp[3];
             float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
             float mx = -INFINITY;
@@ -495,9 +571,13 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
             if (p.idx) p.idx[(size_t)b * p.max_det + r] = a;
         }
         if (p.coeff) {
-            const float* cf = (l == 0 ? cf0 : l == 1 ? cf1 : cf2) + ((size_t)b * HWl + loc) * 32;
+            const float* cf = (MODE == 2 && p.sp_cf) ? p.sp_cf + ((size_t)b * p.max_det + srow) * 32 : (l == 0 ? cf0 : l == 1 ? cf1 : cf2) + ((size_t)b * HWl + loc) * 32;
             for (int j = sd * 8; j < sd * 8 + 8; ++j) p.coeff[((size_t)b * p.max_det + r) * 32 + j] = cf[j];
         }
+    }
+    if constexpr (MODE == 2) {
+        // the position lists of this forward have been consumed (the branch kernels ran between the two stages): empty them for the next one
+        if (b == 0 && tid < 3 && p.sp_pcount) p.sp_pcount[tid] = 0;
     }
     HEAD_STAMP(6);
 }
@@ -506,15 +586,24 @@ hipError_t head_read_clocks(unsigned long long* out8) { return hipMemcpyFromSymb
 
 size_t head_scratch_bytes(int B, int A) { return (size_t)B * A * sizeof(unsigned); }
 
-hipError_t launch_head(const HeadParams& p, hipStream_t st) {
-    if (p.A > CAP || p.max_det > MAXK || (p.scratch == nullptr && p.mk[0] == nullptr)) return hipErrorInvalidValue;
+static hipError_t head_attrs() {
     const size_t sh = (size_t)(CAP + 1536 + HT) * 8 + MAXK * 4 + MAXK * 8;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)head_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipError_t e = hipFuncSetAttribute((const void*)head_select_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_select_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)head_select_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    return hipSuccess;
+}
+
+hipError_t launch_head(const HeadParams& p, hipStream_t st) {
+    if (p.A > CAP || p.max_det > MAXK || (p.scratch == nullptr && p.mk[0] == nullptr)) return hipErrorInvalidValue;
+    const size_t sh = (size_t)(CAP + 1536 + HT) * 8 + MAXK * 4 + MAXK * 8;
+    hipError_t e = head_attrs();
+    if (e != hipSuccess) return e;
     unsigned* mkey = (unsigned*)p.scratch;
     if (p.mk[0]) {
         // class-max keys were produced per level by OP_AMAX
@@ -526,7 +615,25 @@ hipError_t launch_head(const HeadParams& p, hipStream_t st) {
         const long items = (long)p.B * p.A * 16;
         hipLaunchKernelGGL(anchor_max_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, p, mkey);
     }
-    hipLaunchKernelGGL(head_select_kernel, dim3(p.B), dim3(HT), sh, st, p, mkey);
+    hipLaunchKernelGGL(head_select_kernel<0>, dim3(p.B), dim3(HT), sh, st, p, mkey);
+    return hipGetLastError();
+}
+
+// winners-only head: stage 1 (the per-level class-max keys must exist: p.mk), then the caller runs head_branch.hip, then stage 2 + decode
+hipError_t launch_head_stage1(const HeadParams& p, hipStream_t st) {
+    if (p.A > CAP || p.max_det > MAXK || p.mk[0] == nullptr || !p.sp_sel || !p.sp_wlist || !p.sp_wcount || !p.sp_thr) return hipErrorInvalidValue;
+    const size_t sh = (size_t)(CAP + 1536 + HT) * 8 + MAXK * 4 + MAXK * 8;
+    hipError_t e = head_attrs();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(head_select_kernel<1>, dim3(p.B), dim3(HT), sh, st, p, (const unsigned*)nullptr);
+    return hipGetLastError();
+}
+hipError_t launch_head_stage2(const HeadParams& p, hipStream_t st) {
+    if (p.A > CAP || p.max_det > MAXK || !p.sp_sel || !p.sp_thr || !p.sp_box) return hipErrorInvalidValue;
+    const size_t sh = (size_t)(CAP + 1536 + HT) * 8 + MAXK * 4 + MAXK * 8;
+    hipError_t e = head_attrs();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(head_select_kernel<2>, dim3(p.B), dim3(HT), sh, st, p, (const unsigned*)nullptr);
     return hipGetLastError();
 }
 

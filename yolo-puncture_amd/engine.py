@@ -75,6 +75,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_debug_force_conv_cfg.argtypes = [C.c_int]
     lib.yp_debug_ablation.argtypes = [C.c_int]
     lib.yp_debug_head_clocks.argtypes = [C.POINTER(C.c_uint64)]
+    lib.yp_debug_head_branch_clocks.argtypes = [C.POINTER(C.c_uint64)]
     lib.yp_debug_contour_clocks.argtypes = [C.POINTER(C.c_uint64)]
     lib.yp_letterbox.argtypes = [vp, C.c_int, C.c_int, vp] + [C.c_int] * 7 + [vp]
     lib.yp_letterbox.restype = C.c_int
@@ -97,7 +98,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output", "yp_op_input",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_tuning_export", "yp_tuning_import", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_contour_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
+           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_tuning_export", "yp_tuning_import", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_head_branch_clocks", "yp_debug_head_winners", "yp_debug_contour_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy",
            "yp_u2net_create", "yp_u2net_destroy", "yp_u2net_weight_count", "yp_u2net_weight_info", "yp_u2net_set_weight", "yp_u2net_finalize",
            "yp_u2net_forward", "yp_u2net_set_graph", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
@@ -395,6 +396,15 @@ class Engine:
         """Debug: overwrite channels [coff, coff+C) of an engine tensor from an fp32 host tensor [B,H,W,C]."""
         d = data_nhwc.detach().to(torch.float32).contiguous().cpu()
         self._chk(self.lib.yp_tensor_write(self._h, index, coff, int(d.shape[-1]), C.c_void_p(d.data_ptr())))
+
+    def head_winners(self, B: int):
+        """Debug: what the winners-only head left behind the last forward - (mode bits, sel [B,512] int32, box rows [B,max_det,64],
+        coefficient rows [B,max_det,32]); mode 0 = dense head (arrays are then zeros)."""
+        sel = torch.zeros((B, 512), dtype=torch.int32)
+        box = torch.zeros((B, self.max_det, 64), dtype=torch.float32)
+        cf = torch.zeros((B, self.max_det, 32), dtype=torch.float32)
+        mode = self._chk(self.lib.yp_debug_head_winners(self._h, C.c_void_p(sel.data_ptr()), C.c_void_p(box.data_ptr()), C.c_void_p(cf.data_ptr())))
+        return mode, sel, box, cf
 
     def profile(self, im: torch.Tensor, iters: int = 5) -> List[dict]:
         """Per-op HIP-event timing (eager, one event pair per launch) on the current stream."""
