@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL and run the all-gather even with one rank (rehearsal of the N>1 path on a 1-GPU box; launch under torch.distributed.run)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--in-flight", type=int, default=0, help="batches in flight per GPU (parallel.EngineRing: that many engines take the steps round-robin); 1 = one engine, one step after the other; "
+                    "0 (default) = 2 if an untimed trial before the warm-up finds it faster on this box than 1, else 1")
     ap.add_argument("--no-dense-head", action="store_true", help="skip the comparison leg that times the same step with every head branch dense")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -147,16 +149,39 @@ def main():
     eng.set_graph(not a.no_graph)
     if a.no_lanes and not a.no_graph:
         eng._chk(eng.lib.yp_set_graph(eng._h, 2))
+    # several batches in flight (parallel.EngineRing): engine j takes steps j, j+n, ... on its own stream, so that the low-occupancy end of
+    # one step (20x20 layers, top-k) runs beside the start of the next. Every engine has its own arena, graph and output buffers and the
+    # same tile configurations; every step is a complete forward + post-process of its 32 frames.
+    auto_fl = a.in_flight <= 0 and not a.no_graph
+    n_fl = (2 if auto_fl else max(1, a.in_flight)) if not a.no_graph else 1
+    from yolo_puncture_amd.parallel import EngineRing
+    ring = EngineRing([eng] + [Engine(a.variant, 80, a.seg, a.dtype, local, state=st) for _ in range(n_fl - 1)])
+    if n_fl > 1:
+        ring.prepare(frames)                               # engine 0's tile configurations to the others, every graph captured (without lanes)
+    outs = [out] + [{k: (torch.empty_like(v) if v is not None else None) for k, v in out.items()} for _ in range(n_fl - 1)]
+    lanes = ring.streams if n_fl > 1 else [None]
 
-    def step():
-        eng.forward(frames, out)
+    def step_on(j):
+        ring.engines[j].forward(frames, outs[j])
         if use_dist:
             i = nstep[0] & 1
-            nstep[0] += 1
             if pending[i] is not None:
                 pending[i].wait()                   # the gather that last used this pair of buffers has finished
-            send[i].copy_(out["det"])
+            send[i].copy_(outs[j]["det"])
             pending[i] = dist.all_gather_into_tensor(gath[i], send[i], async_op=True)
+
+    def lanes_mode(on):                                    # engine 0 alone replays a graph with concurrent head lanes, in a ring one chain
+        if not a.no_graph:
+            eng.set_graph(1 if (on and not a.no_lanes) else 2)
+
+    def step():
+        j = nstep[0] % n_fl
+        if n_fl > 1:
+            with torch.cuda.stream(lanes[j]):
+                step_on(j)
+        else:
+            step_on(0)
+        nstep[0] += 1
 
     def sync():
         for h in pending:
@@ -170,6 +195,32 @@ def main():
     # the steps run under a side stream: the engine replays its graph on the caller's stream when that is not the legacy null stream
     # (no hop to a stream of its own and back between steps: -25 us per step)
     side = torch.cuda.Stream(dev)
+    fl_trial = None
+    if auto_fl:
+        # how well two batches overlap depends on how the runtime maps the streams in play onto its hardware queues (with 8 queues instead
+        # of the default 4 two in flight are SLOWER than one on the same box): a short untimed trial decides, all ranks together
+        fl_trial = {}
+        with torch.cuda.stream(side):
+            for cand in (2, 1):
+                n_fl = cand
+                lanes_mode(cand == 1)
+                nstep[0] = 0
+                for _ in range(4):
+                    step()
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(16):
+                    step()
+                sync()
+                tt = time.perf_counter() - t0
+                if use_dist:
+                    t = torch.tensor([tt], dtype=torch.float64, device=dev)
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                    tt = float(t.item())
+                fl_trial[cand] = round(tt / 16 * 1e3, 4)
+        n_fl = 2 if fl_trial[2] < fl_trial[1] else 1
+        lanes_mode(n_fl == 1)
+        nstep[0] = 0
     with torch.cuda.stream(side):
         for _ in range(a.warmup):
             step()
@@ -185,6 +236,20 @@ def main():
         dt = float(t.item())
     ms_per_step = dt / a.steps * 1e3
     value = world * B * a.steps / dt
+    one_fl = None
+    if n_fl > 1 and rank == 0 and world == 1:
+        # the same K steps with ONE batch in flight (engine 0 alone, one step after the other): what a caller without a next batch ready sees
+        lanes_mode(True)
+        with torch.cuda.stream(side):
+            for _ in range(max(a.warmup, 2)):
+                eng.forward(frames, out)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(a.steps):
+                eng.forward(frames, out)
+            torch.cuda.synchronize(dev)
+            dt1 = time.perf_counter() - t0
+        one_fl = {"ms_per_step": round(dt1 / a.steps * 1e3, 4), "value": round(B * a.steps / dt1, 1)}
 
     head_note = {"box_branch": "dense (YOLOP_DENSE_HEAD=1)" if os.environ.get("YOLOP_DENSE_HEAD") == "1" else
                  "evaluated at the positions the top-k winners' 3x3 neighbourhoods cover (head_branch.hip): the rows v10postprocess gathers, "
@@ -197,10 +262,11 @@ def main():
             "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"YOLOv10-{a.variant.upper()}{'-seg' if a.seg else ''} {S}x{S} bs={B}/GPU {a.dtype}, "
                                    f"u8 frames resident in HBM -> [B,300,6] detections"
+                                   + (f", {n_fl} batches in flight" if n_fl > 1 else "")
                                    + (", RCCL all-gather of detections" if world > 1 else ""),
                        "global_batch": world * B, "imgsz": S, "parallelism": f"frame-shard x{world}",
                        "weights": "seeded synthetic (SURVEY 8d)", "hipgraph": not a.no_graph,
-                       "head": head_note},
+                       "in_flight": n_fl, "in_flight_trial_ms": fl_trial, "one_in_flight": one_fl, "head": head_note},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if partial:
@@ -295,7 +361,8 @@ def main():
             raise SystemExit("all-gather returned different detections than the local shard")
         dist.barrier()
         dist.destroy_process_group()
-    eng.close()
+    for e2 in ring.engines:
+        e2.close()
 
 
 if __name__ == "__main__":

@@ -5,8 +5,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 export YOLOP_TUNE_CACHE=${YOLOP_TUNE_CACHE:-/tmp/ab_tune}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/kst
-python3 $R/bench.py --no-cpu-baseline --no-roofline --no-dense-head --steps 20 "$@" > /dev/null 2>&1     # fills the tune cache
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-dense-head --steps 20 "$@" > /tmp/kst.log 2>&1
+python3 $R/bench.py --no-cpu-baseline --no-roofline --no-dense-head --in-flight ${IN_FLIGHT:-1} --steps 20 "$@" > /dev/null 2>&1     # fills the tune cache
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kst -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-dense-head --in-flight ${IN_FLIGHT:-1} --steps 20 "$@" > /tmp/kst.log 2>&1
 python3 - "$F" <<'PY'
 import csv, glob, re, sys
 f = glob.glob("/tmp/kst/*/*_kernel_stats.csv")[0]

@@ -201,7 +201,8 @@ __device__ void trace_segment(const Bitmap& bm, const unsigned* cbm, int bw, int
 // Summed over a closed border the bit says whether q lies inside the polygon through the border's pixel centres; pieces walked twice
 // (one-pixel-wide parts) cancel. Same walk as trace_segment / moore_trace.
 template <bool SEG>
-__device__ unsigned long long walk_parity(const Bitmap& bm, const unsigned* cbm, int bw, int sy, int sx, int max_steps, const int* qy, const int* qx, int nq) {
+__device__ unsigned long long walk_parity(const Bitmap& bm, const unsigned* cbm, int bw, int sy, int sx, int max_steps, const int* qy, const int* qx, int nq,
+                                          const unsigned long long* rowq = nullptr) {
     const int start_lin = sy * bw + sx;
     int cy = sy, cx = sx, rb = sy * bm.pitch, lin = start_lin;
     unsigned long long tog = 0ull;
@@ -212,6 +213,17 @@ __device__ unsigned long long walk_parity(const Bitmap& bm, const unsigned* cbm,
     auto cross = [&](int y1, int x1, int y2, int x2) {
         if (y1 == y2) return;
         const int ylo = min(y1, y2), xa = (y1 < y2) ? x1 : x2;      // the end point on the upper row (the row a query must be on)
+        if (rowq) {
+            // rowq[y] = the queries on row y as a bit set: one LDS read per move instead of two per (move, query) - with 40 borders in a
+            // mask that loop was 0.85 of the 0.9 ms the kernel took
+            unsigned long long m = rowq[ylo];
+            while (m) {
+                const int q = __builtin_ctzll(m);
+                m &= m - 1ull;
+                if (xa > qx[q]) tog ^= 1ull << q;
+            }
+            return;
+        }
         for (int q = 0; q < nq; ++q)
             if (qy[q] == ylo && xa > qx[q]) tog ^= 1ull << q;
     };
@@ -355,11 +367,16 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     int my_np[CPT];
     // the list's head (region 0) takes the result; regions 1 .. nslots behind it are the candidates' own lists
     const int slot_cap = p.max_pts >= 8 * CT_SLOT_PTS ? CT_SLOT_PTS : p.max_pts / 8;
-    const int nslots = slot_cap >= 8 ? min(CT_MAXSLOTS, p.max_pts / slot_cap - 1) : 0;
+    // the assembled list grows from the region's start; the candidates' slots begin behind head_cap points (a one-mask call has room for a
+    // 16-slot head: "all" lists of a few thousand points are then still copied out of the slots in parallel instead of re-traced by one lane)
+    const int head_cap = p.max_pts >= 48 * slot_cap ? 16 * slot_cap : slot_cap;
+    const int nslots = slot_cap >= 8 ? min(CT_MAXSLOTS, (p.max_pts - head_cap) / slot_cap) : 0;
     // outer borders found (their leaders): candidate index, points, start point kept, start pixel, external?
     __shared__ int s_nl, s_no, s_total;
     __shared__ int l_k[CT_NLMAX], l_np[CT_NLMAX], l_sk[CT_NLMAX], l_y[CT_NLMAX], l_x[CT_NLMAX], l_ext[CT_NLMAX], l_ord[CT_NLMAX], l_base[CT_NLMAX];
     __shared__ unsigned long long l_par[CT_NLMAX];
+    constexpr int CT_QROWS = 1024;                // rows the per-row query sets cover (a taller box takes the plain loop)
+    __shared__ unsigned long long q_row[CT_QROWS];
     __shared__ int s_stored[CT_MAXSLOTS];         // one-lane path: points a candidate with a slot stored in it
     __shared__ unsigned long long s_key;          // "largest" among more than CT_NLMAX borders: the round's best (points, start, candidate)
     __shared__ int s_in, s_qw[2];                 // ... is it inside another border? its start pixel (y, x)
@@ -415,7 +432,7 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
             const int lin = cand[k];
             const int sy = lin / bw, sx = lin - sy * bw;
             SegInfo si;
-            if (k < nslots) trace_segment<true>(bm, cbm, bw, sy, sx, max_steps, out + (size_t)(k + 1) * slot_cap * 2, slot_cap, bx0, by0, si);
+            if (k < nslots) trace_segment<true>(bm, cbm, bw, sy, sx, max_steps, out + 2 * ((size_t)head_cap + (size_t)k * slot_cap), slot_cap, bx0, by0, si);
             else trace_segment<false>(bm, cbm, bw, sy, sx, max_steps, nullptr, 0, bx0, by0, si);
             nxt[k] = si.next_lin >= 0 ? find(si.next_lin) : -1;
             nkp[k] = si.nkeep; nmv[k] = si.nmoves; mvs[k] = si.first_move | (si.last_move << 4); mnl[k] = si.min_lin;
@@ -491,11 +508,18 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
             }
             if (!found) { decline(-2); return; }
         } else if (nl >= 2) {                                      // 3c. which outer borders lie inside another one?
+            const bool use_rows = bh <= CT_QROWS;
+            if (use_rows) {
+                for (int i = tid; i < bh; i += CT_THREADS) q_row[i] = 0ull;
+                __syncthreads();
+                if (tid < nl) atomicOr(&q_row[l_y[tid]], 1ull << tid);
+                __syncthreads();
+            }
             for (int k = tid; k < ncand; k += CT_THREADS) {
                 if (bid[k] < 0) continue;
                 const int own = jkp[bid[k]];
                 const int lin = cand[k];
-                unsigned long long t = walk_parity<true>(bm, cbm, bw, lin / bw, lin % bw, max_steps, l_y, l_x, nl);
+                unsigned long long t = walk_parity<true>(bm, cbm, bw, lin / bw, lin % bw, max_steps, l_y, l_x, nl, use_rows ? q_row : nullptr);
                 t &= ~(1ull << own);
                 if (t) atomicXor(&l_par[own], t);
             }
@@ -517,7 +541,7 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
             const int lin = cand[k];
             const int sy = lin / bw, sx = lin - sy * bw;
             int kept0 = 0, stored = 0, np;
-            if (k < nslots) np = moore_trace<true>(bm, bw, sy, sx, max_steps, out + (size_t)(k + 1) * slot_cap * 2, slot_cap, bx0, by0, &kept0, &stored);
+            if (k < nslots) np = moore_trace<true>(bm, bw, sy, sx, max_steps, out + 2 * ((size_t)head_cap + (size_t)k * slot_cap), slot_cap, bx0, by0, &kept0, &stored);
             else np = moore_trace<false>(bm, bw, sy, sx, max_steps, nullptr, 0, bx0, by0, &kept0, &stored);
             if (k < nslots) s_stored[k] = stored;
             if (np > 0) {
@@ -531,6 +555,13 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
         const int ns = s_nl;
         if (ns >= 2 && p.strategy == 1) {
             if (ns > CT_NLMAX) { decline(-2); return; }
+            const bool use_rows = bh <= CT_QROWS;
+            if (use_rows) {
+                for (int i = tid; i < bh; i += CT_THREADS) q_row[i] = 0ull;
+                __syncthreads();
+                if (tid < ns) atomicOr(&q_row[l_y[tid]], 1ull << tid);
+                __syncthreads();
+            }
 #pragma unroll
             for (int i = 0; i < CPT; ++i) {
                 const int k = tid + i * CT_THREADS;
@@ -538,7 +569,7 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
                 int own = 0;
                 while (l_k[own] != k) ++own;
                 const int lin = cand[k];
-                unsigned long long t = walk_parity<false>(bm, nullptr, bw, lin / bw, lin % bw, max_steps, l_y, l_x, ns);
+                unsigned long long t = walk_parity<false>(bm, nullptr, bw, lin / bw, lin % bw, max_steps, l_y, l_x, ns, use_rows ? q_row : nullptr);
                 t &= ~(1ull << own);
                 if (t) atomicXor(&l_par[own], t);
             }
@@ -616,10 +647,71 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
     __syncthreads();
     const int no = s_no, total = s_total;
     if (no == 0 || total > p.max_pts) { decline(no == 0 ? 0 : -2); return; }
-    // the head region (slot_cap points) holds the whole list when every contour is to be copied out of the candidates' slots; a longer
+    // the head region (head_cap points) holds the whole list when every contour is to be copied out of the candidates' slots; a longer
     // list is re-traced contour by contour by one lane straight into place (it may then run over the slots: nothing reads them any more)
-    const bool copy_ok = total <= slot_cap;
-    for (int a = 0; a < no; ++a) {
+    const bool copy_ok = total <= head_cap;
+    const bool par_all = seg_mode && copy_ok;
+    if (par_all) {
+        // every contour at once: (A) one lane per contour walks its cycle of segments and fixes each segment's output offset and joint
+        // point, (B) a wave per SEGMENT - whatever contour it belongs to - copies the segment's points out of its slot, (C) what (A)
+        // declined is re-traced by one lane. (One contour after the other - a serial cycle walk and three barriers each - cost 280 us for
+        // the 40 contours of an "all" list.)
+        __shared__ int l_ok[CT_NLMAX], l_apos[CT_NLMAX];
+        if (tid < nl) l_apos[tid] = -1;
+        __syncthreads();
+        if (tid < no) l_apos[l_ord[tid]] = tid;
+        if (tid < nl) cyc[l_k[tid]] = tid;                          // leader's candidate index -> its row of the table (cyc is free here)
+        __syncthreads();
+        if (tid < no) {
+            const int li = l_ord[tid], kb = l_k[li], npq = l_np[li], rotq = l_sk[li], base = l_base[tid];
+            bool ok = true;
+            int off = base + rotq, j = kb, moves = 0, prev = -1, len = 0;
+            while (ok) {
+                if (j >= nslots || nkp[j] > slot_cap) { ok = false; break; }
+                const int jn = nxt[j];
+                const int joint = (prev >= 0 && (((mvs[prev] >> 4) & 15) != (mvs[j] & 15))) ? 1 : 0;   // the joint point at this segment's start
+                jkp[j] = joint;
+                off += joint;
+                moves += nmv[j];
+                const int myoff = off;
+                off += nkp[j];
+                nmv[j] = myoff;                                    // (moves are no longer needed: the slot becomes the offset)
+                prev = j;
+                ++len;
+                j = jn;
+                if (j == kb) break;
+                if (len >= ncand) { ok = false; break; }
+            }
+            if (ok && (moves <= 2 || off != base + npq)) ok = false;      // tiny borders and any disagreement go the serial way
+            l_ok[tid] = ok ? 1 : 0;
+            if (ok && rotq) { out[2 * base] = l_x[li] + bx0; out[2 * base + 1] = l_y[li] + by0; }
+        }
+        __syncthreads();
+        for (int k = wave; k < ncand; k += CT_THREADS / 64) {
+            const int b = bid[k];
+            if (b < 0) continue;
+            const int li = cyc[b];
+            if ((unsigned)li >= (unsigned)nl || l_k[li] != b) continue;
+            const int a = l_apos[li];
+            if (a < 0 || !l_ok[a]) continue;
+            const int o0 = nmv[k];
+            if (lane == 0 && jkp[k]) { const int l = cand[k]; const int yy = l / bw, xx = l - yy * bw; out[2 * (o0 - 1)] = xx + bx0; out[2 * (o0 - 1) + 1] = yy + by0; }
+            const int32_t* sp = out + 2 * ((size_t)head_cap + (size_t)k * slot_cap);
+            for (int q = lane; q < 2 * nkp[k]; q += 64) out[2 * o0 + q] = sp[q];
+        }
+        if (tid == 0) {
+            for (int a = 0; a < no; ++a) {
+                if (l_ok[a]) continue;
+                const int li = l_ord[a], rotq = l_sk[li], base = l_base[a];
+                int kept0 = 0, stored = 0;
+                moore_trace<true>(bm, bw, l_y[li], l_x[li], max_steps, out + 2 * (base + rotq), p.max_pts - base - rotq, bx0, by0, &kept0, &stored);
+                if (rotq) { out[2 * base] = l_x[li] + bx0; out[2 * base + 1] = l_y[li] + by0; }
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (int a = 0; a < (par_all ? 0 : no); ++a) {
         const int li = l_ord[a], kb = l_k[li], npq = l_np[li], rotq = l_sk[li], base = l_base[a];
         const int sy = l_y[li], sx = l_x[li];
         __shared__ int s_cyc_len, s_par_ok;
@@ -662,12 +754,12 @@ __global__ __launch_bounds__(CT_THREADS) void contour_kernel(const ContourParams
                 const int j = cyc[i];
                 const int o0 = nmv[j];
                 if (lane == 0 && jkp[j]) { const int l = cand[j]; const int yy = l / bw, xx = l - yy * bw; out[2 * (o0 - 1)] = xx + bx0; out[2 * (o0 - 1) + 1] = yy + by0; }
-                const int32_t* sp = out + (size_t)(j + 1) * slot_cap * 2;
+                const int32_t* sp = out + 2 * ((size_t)head_cap + (size_t)j * slot_cap);
                 for (int q = lane; q < 2 * nkp[j]; q += 64) out[2 * o0 + q] = sp[q];
             }
             if (tid == 0 && rotq) { out[2 * base] = sx + bx0; out[2 * base + 1] = sy + by0; }
         } else if (s_par_ok) {
-            const int32_t* sp = out + (size_t)(kb + 1) * slot_cap * 2;
+            const int32_t* sp = out + 2 * ((size_t)head_cap + (size_t)kb * slot_cap);
             for (int j = tid; j < 2 * (npq - rotq); j += CT_THREADS) out[2 * (base + rotq) + j] = sp[j];
             if (tid == 0 && rotq) { out[2 * base] = sx + bx0; out[2 * base + 1] = sy + by0; }
         } else if (tid == 0) {
