@@ -1269,16 +1269,6 @@ static int autotune(yp_engine& e) {
     };
     const uint8_t* tune_in = e.tune_input;
     RunArgs warm{tune_in, nullptr, nullptr, nullptr};
-    // YOLOP_TUNE_PAIR=1: rank configurations by the time TWO concurrent instances of the layer take (two streams) - with two batches in flight
-    // (parallel.EngineRing) what a layer costs is the CU time it holds, not how soon one instance alone is done
-    static const bool pair_mode = [] { const char* v = std::getenv("YOLOP_TUNE_PAIR"); return v && *v == '1'; }();
-    hipStream_t sA = nullptr, sB = nullptr;
-    hipEvent_t e2 = nullptr;
-    if (pair_mode) {
-        HIPCHK(hipStreamCreateWithFlags(&sA, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&sB, hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-    }
     auto time_cfg = [&](Op& o, float& tmin) -> hipError_t {
         tmin = 1e30f;
         const Op* prod = (cold_mode == 2) ? producer_of(o) : nullptr;
@@ -1291,22 +1281,10 @@ static int autotune(yp_engine& e) {
                 if (pe != hipSuccess) return pe;
             }
             hipError_t ee;
-            if (pair_mode) {
-                if ((ee = hipStreamSynchronize(nullptr)) != hipSuccess) return ee;          // (flush / producer ran on the null stream)
-                if ((ee = hipEventRecord(e0, sA)) != hipSuccess) return ee;
-                if ((ee = hipStreamWaitEvent(sB, e0, 0)) != hipSuccess) return ee;
-                hipError_t err = run_op(e, o, none, sB);
-                if (err == hipSuccess) err = run_op(e, o, none, sA);
-                if (err != hipSuccess) return err;
-                if ((ee = hipEventRecord(e2, sB)) != hipSuccess) return ee;
-                if ((ee = hipStreamWaitEvent(sA, e2, 0)) != hipSuccess) return ee;
-                if ((ee = hipEventRecord(e1, sA)) != hipSuccess) return ee;
-            } else {
             if ((ee = hipEventRecord(e0, nullptr)) != hipSuccess) return ee;
             hipError_t err = run_op(e, o, none, nullptr);
             if (err != hipSuccess) return err;
             if ((ee = hipEventRecord(e1, nullptr)) != hipSuccess) return ee;
-            }
             if ((ee = hipEventSynchronize(e1)) != hipSuccess) return ee;
             float ms = 0;
             if ((ee = hipEventElapsedTime(&ms, e0, e1)) != hipSuccess) return ee;
@@ -1383,9 +1361,6 @@ static int autotune(yp_engine& e) {
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    if (e2) (void)hipEventDestroy(e2);
-    if (sA) (void)hipStreamDestroy(sA);
-    if (sB) (void)hipStreamDestroy(sB);
     if (flush) (void)hipFree(flush);
     return YP_OK;
 }
