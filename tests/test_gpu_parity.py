@@ -314,24 +314,27 @@ def test_end_to_end_bf16_accuracy(variant, seg, shape, dense, monkeypatch):
     eng.close()
 
 
-@pytest.mark.parametrize("variant,seg,shape", [("s", True, (3, 160, 192)), ("n", False, (2, 256, 384)), ("s", False, (1, 480, 608)), ("m", True, (1, 96, 128))])
-def test_winners_only_head_equals_dense(variant, seg, shape, monkeypatch):
+@pytest.mark.parametrize("variant,seg,shape,nc", [("s", True, (3, 160, 192), 80), ("n", False, (2, 256, 384), 80), ("s", False, (1, 480, 608), 80), ("m", True, (1, 96, 128), 80),
+                                                  ("n", False, (2, 128, 160), 3), ("s", True, (2, 96, 128), 1), ("n", False, (5, 32, 64), 80)])
+def test_winners_only_head_equals_dense(variant, seg, shape, nc, monkeypatch):
     """The default head evaluates the box branch (and the coefficient branch where its width is 32) at the top-k winners only
     (head_branch.hip). Against the same engine with every branch dense (YOLOP_DENSE_HEAD=1): anchors, classes and scores are bit-identical
     (they depend on the class branch alone); the winners' box logits / coefficients are the dense maps' values at those anchors up to fp32
     summation order through two bf16-rounded intermediates - almost all of them within 1e-3 of the map's range, none beyond 5 %; boxes
-    move by a fraction of a pixel. Frame borders (zero padding of both 3x3 convolutions) are part of every case: winners sit on them."""
-    st, im = make_case(variant, 80, seg, 0, shape)
+    move by a fraction of a pixel. Frame borders (zero padding of both 3x3 convolutions) are part of every case: winners sit on them.
+    Also: class counts 1 / 3 (the reference's needle checkpoints) and a frame with fewer anchors than max_det (every anchor a winner,
+    every position listed)."""
+    st, im = make_case(variant, nc, seg, 0, shape)
     imc = im.cuda()
     B = shape[0]
-    sp = _engine(variant, 80, seg, "bf16", st)
+    sp = _engine(variant, nc, seg, "bf16", st)
     sp.set_autotune(False)
     out_s = {k: v.cpu() for k, v in sp.forward(imc).items() if v is not None}
     mode, sel, rows, cfrows = sp.head_winners(B)
     assert mode & 1, "the box branch should run winners-only for this model"
     sp.close()
     monkeypatch.setenv("YOLOP_DENSE_HEAD", "1")
-    de = _engine(variant, 80, seg, "bf16", st)
+    de = _engine(variant, nc, seg, "bf16", st)
     de.set_autotune(False)
     out_d = {k: v.cpu() for k, v in de.forward(imc).items() if v is not None}
     assert de.head_winners(B)[0] == 0
