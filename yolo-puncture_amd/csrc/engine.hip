@@ -735,10 +735,11 @@ static HeadBranchParams head_branch_params(const yp_engine& e, const Op& h, int 
     }
     p.B = e.pB; p.max_det = e.desc.max_det; p.maxk = HEAD_MAXK;
     p.A0 = p.H[0] * p.W[0]; p.A1 = p.H[1] * p.W[1];
-    p.sel = (const int*)(base + ws.sel); p.wlist = (const int*)(base + ws.wlist); p.wcount = (const int*)(base + ws.wcount);
-    p.out = (float*)(base + (which == 0 ? ws.box : ws.cf));
-    p.plist = (const int*)(base + ws.plist); p.pcount = (const int*)(base + ws.pcount);
-    p.t0 = base + (which == 0 ? ws.t0box : ws.t0cf); p.t0_bytes = ws.rows * (size_t)p.cmid * 2;
+    auto at = [&](size_t off) -> char* { return base ? base + off : nullptr; };      // (plan time: the workspace does not exist yet)
+    p.sel = (const int*)at(ws.sel); p.wlist = (const int*)at(ws.wlist); p.wcount = (const int*)at(ws.wcount);
+    p.out = (float*)at(which == 0 ? ws.box : ws.cf);
+    p.plist = (const int*)at(ws.plist); p.pcount = (const int*)at(ws.pcount);
+    p.t0 = at(which == 0 ? ws.t0box : ws.t0cf); p.t0_bytes = ws.rows * (size_t)p.cmid * 2;
     for (int l = 0; l < 3; ++l) { p.plist_off[l] = ws.plist_off[l]; p.plist_cap[l] = ws.plist_cap[l]; p.t0_off[l] = ws.t0_off[l] * (size_t)p.cmid; }
     p.pos_grid = 256;                        // one workgroup per CU (its three plane slots fill most of a CU's LDS)
     return p;
