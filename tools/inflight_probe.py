@@ -1,6 +1,8 @@
 """A/B probe: N batches in flight. N engines (own arena, own graph, own stream; same weights) take the steps round-robin, each
 on its own torch stream, so that the low-occupancy parts of one batch's graph (the 20x20 tail, the top-k kernel: 100-400
-workgroups on 256 CUs) run beside another batch's kernels. Prints images/s for N = 1, 2, 3 on the same box.
+workgroups on 256 CUs) run beside another batch's kernels. Prints images/s for N = 1, 2, 3 on the same box. (The probe that led to
+parallel.EngineRing; its graphs keep their head lanes, so its numbers depend on the runtime's stream -> hardware-queue mapping - DESIGN 4,
+round 3. bench.py --in-flight N measures the ring itself.)
     python tools/inflight_probe.py [--steps 40]"""
 import argparse
 import os
