@@ -1,6 +1,9 @@
 // On-box peaks the roofline fractions are priced against (SURVEY 8d asks for them beside the nominal figures):
 //   bf16 MFMA   v_mfma_f32_16x16x32_bf16 back to back, operands in registers, 4 and 8 waves per CU (1 and 2 per SIMD), random data
 //   HBM         float4 copy of 1 GiB (read + write counted), and a read-only sum
+//   L2 -> CU    every workgroup re-reads a small region that stays in its XCD's L2: 2 MB shared by all (the weights' case) and a private
+//               64 KB per workgroup (16 MB in all: L2-resident per XCD, nothing shared), float4 loads, 8 waves per CU - the rate a CU can
+//               take operands in at, whatever path brings them
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -56,6 +59,18 @@ __global__ __launch_bounds__(256) void read_kernel(const float4* __restrict__ sr
     if (acc == 123.456f) sink[0] = acc;
 }
 
+// Each workgroup sweeps `span` bytes (a multiple of 16 KiB) starting at base + (shared ? 0 : blockIdx.x * span), `reps` times.
+__global__ __launch_bounds__(512) void l2_read_kernel(const float4* __restrict__ src, float* sink, size_t span_f4, int reps, int shared) {
+    const float4* p = src + (shared ? 0 : (size_t)blockIdx.x * span_f4);
+    float acc = 0.f;
+    for (int r = 0; r < reps; ++r)
+        for (size_t i = threadIdx.x; i < span_f4; i += 512 * 8) {                                  // eight 16-byte loads per lane in flight (64 KB per CU)
+            const float4 v0 = p[i], v1 = p[i + 512], v2 = p[i + 1024], v3 = p[i + 1536], v4 = p[i + 2048], v5 = p[i + 2560], v6 = p[i + 3072], v7 = p[i + 3584];
+            acc += v0.x + v1.y + v2.z + v3.w + v4.x + v5.y + v6.z + v7.w;
+        }
+    if (acc == 123.456f) sink[0] = acc;
+}
+
 int main() {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     float *seed, *sink;
@@ -102,6 +117,22 @@ int main() {
             float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
         }
         printf("%s 1 GiB: %.0f GB/s (%.3f ms)\n", pass == 0 ? "float4 copy (read+write)" : "float4 read", (pass == 0 ? 2.0 : 1.0) * bytes / best * 1e-6, best);
+    }
+    for (int shared = 1; shared >= 0; --shared) {
+        const size_t span = shared ? (2u << 20) : (64u << 10);          // bytes per workgroup sweep
+        const int reps = shared ? 40 : 1280;
+        hipLaunchKernelGGL(l2_read_kernel, dim3(256), dim3(512), 0, 0, (const float4*)a, sink, span / 16, 2, shared);
+        CHECK(hipDeviceSynchronize());
+        float best = 1e30f;
+        for (int r = 0; r < 3; ++r) {
+            CHECK(hipEventRecord(e0)); hipLaunchKernelGGL(l2_read_kernel, dim3(256), dim3(512), 0, 0, (const float4*)a, sink, span / 16, reps, shared); CHECK(hipEventRecord(e1));
+            CHECK(hipDeviceSynchronize());
+            float ms; CHECK(hipEventElapsedTime(&ms, e0, e1)); if (ms < best) best = ms;
+        }
+        const double bytes_cu = (double)span * reps;
+        printf("L2-resident read, %s: %.1f GB/s per CU = %.1f B/clk/CU at 2.4 GHz (%.1f TB/s over 256 CUs; %.3f ms)\n",
+               shared ? "one 2-MB region shared by all workgroups" : "a private 64-KB region per workgroup", bytes_cu / best * 1e-6, bytes_cu / best * 1e-6 / 2.4,
+               256.0 * bytes_cu / best * 1e-9, best);
     }
     return 0;
 }
