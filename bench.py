@@ -155,9 +155,17 @@ def main():
     auto_fl = a.in_flight <= 0 and not a.no_graph
     n_fl = (2 if auto_fl else max(1, a.in_flight)) if not a.no_graph else 1
     from yolo_puncture_amd.parallel import EngineRing
-    ring = EngineRing([eng] + [Engine(a.variant, 80, a.seg, a.dtype, local, state=st) for _ in range(n_fl - 1)])
-    if n_fl > 1:
-        ring.prepare(frames)                               # engine 0's tile configurations to the others, every graph captured (without lanes)
+    ring_note = None
+    try:
+        ring = EngineRing([eng] + [Engine(a.variant, 80, a.seg, a.dtype, local, state=st) for _ in range(n_fl - 1)])
+        if n_fl > 1:
+            ring.prepare(frames)                           # engine 0's tile configurations to the others, every graph captured (without lanes)
+    except Exception as ex:
+        if not auto_fl or use_dist:                        # (asked for explicitly, or other ranks would go on without this one)
+            raise
+        ring_note = f"second engine unavailable ({type(ex).__name__}: {ex}): one batch in flight"
+        ring, n_fl, auto_fl = EngineRing([eng]), 1, False
+        eng.set_graph(2 if a.no_lanes else True)
     outs = [out] + [{k: (torch.empty_like(v) if v is not None else None) for k, v in out.items()} for _ in range(n_fl - 1)]
     lanes = ring.streams if n_fl > 1 else [None]
 
@@ -266,7 +274,7 @@ def main():
                                    + (", RCCL all-gather of detections" if world > 1 else ""),
                        "global_batch": world * B, "imgsz": S, "parallelism": f"frame-shard x{world}",
                        "weights": "seeded synthetic (SURVEY 8d)", "hipgraph": not a.no_graph,
-                       "in_flight": n_fl, "in_flight_trial_ms": fl_trial, "one_in_flight": one_fl, "head": head_note},
+                       "in_flight": n_fl, "in_flight_trial_ms": fl_trial if ring_note is None else ring_note, "one_in_flight": one_fl, "head": head_note},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if partial:
