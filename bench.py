@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--in-flight", type=int, default=0, help="batches in flight per GPU (parallel.EngineRing: that many engines take the steps round-robin); 1 = one engine, one step after the other; "
                     "0 (default) = 2 if an untimed trial before the warm-up finds it faster on this box than 1, else 1")
+    ap.add_argument("--no-one-in-flight", action="store_true", help="skip the comparison leg that repeats the steps with one batch in flight")
     ap.add_argument("--no-dense-head", action="store_true", help="skip the comparison leg that times the same step with every head branch dense")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the bounded CPU-baseline sample")
     return ap.parse_args()
@@ -245,7 +246,7 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     value = world * B * a.steps / dt
     one_fl = None
-    if n_fl > 1 and rank == 0 and world == 1:
+    if n_fl > 1 and rank == 0 and world == 1 and not a.no_one_in_flight:
         # the same K steps with ONE batch in flight (engine 0 alone, one step after the other): what a caller without a next batch ready sees
         lanes_mode(True)
         with torch.cuda.stream(side):
