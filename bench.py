@@ -53,19 +53,22 @@ def parse():
                     "0 (default) = 2 if an untimed trial before the warm-up finds it faster on this box than 1, else 1")
     ap.add_argument("--no-one-in-flight", action="store_true", help="skip the comparison leg that repeats the steps with one batch in flight")
     ap.add_argument("--no-dense-head", action="store_true", help="skip the comparison leg that times the same step with every head branch dense")
+    ap.add_argument("--no-steady", action="store_true", help="skip the >= 200-step repetition of the timed loop (spread of the step time)")
+    ap.add_argument("--no-spread", action="store_true", help="skip the leg with equal class biases on the three levels (winners on P3 / P4 / P5)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames in the bounded CPU-baseline sample")
     return ap.parse_args()
 
 
-def measured_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/traffic_latest.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate rocprofv3 --pmc runs of this command, FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for wide coalesced reads on gfx950). None when no measurement exists for this symbol."""
+def op_traffic() -> dict:
+    """HBM bytes per launch, keyed by OP NAME (profiles/op_traffic.json, written by tools/op_traffic.py from two rocprofv3 --pmc passes of
+    this workload - FETCH_SIZE and WRITE_SIZE collected separately, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide
+    coalesced reads on gfx950; every op's dispatches are bracketed by marker kernels, so the rows do not depend on which tile
+    configuration - i.e. which device symbol - the tuner picked on the profiled box). {} when the file is absent."""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
-        return t["kernels"].get(kernel)
+        t = json.load(open(os.path.join(ROOT, "profiles", "op_traffic.json")))
+        return {k: int(v) for k, v in t["ops"].items()}
     except Exception:
-        return None
+        return {}
 
 
 def usable_cores() -> int:
@@ -264,6 +267,9 @@ def main():
                  "evaluated at the positions the top-k winners' 3x3 neighbourhoods cover (head_branch.hip): the rows v10postprocess gathers, "
                  "same values as the dense maps up to fp32 summation order; dense_head = the same step with every branch dense"}
 
+    failures = []                                              # cross-checks that did not hold: reported in the line, non-zero exit at the end
+    steady = None
+
     def line(roof, cpu, partial):
         d = {
             "metric": "images/sec", "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": a.steps,
@@ -275,7 +281,8 @@ def main():
                                    + (", RCCL all-gather of detections" if world > 1 else ""),
                        "global_batch": world * B, "imgsz": S, "parallelism": f"frame-shard x{world}",
                        "weights": "seeded synthetic (SURVEY 8d)", "hipgraph": not a.no_graph,
-                       "in_flight": n_fl, "in_flight_trial_ms": fl_trial if ring_note is None else ring_note, "one_in_flight": one_fl, "head": head_note},
+                       "in_flight": n_fl, "in_flight_trial_ms": fl_trial if ring_note is None else ring_note, "one_in_flight": one_fl,
+                       "steady": steady, "head": head_note, "checks": "ok" if not failures else failures},
             "roofline": roof, "cpu_baseline": cpu,
         }
         if partial:
@@ -289,26 +296,69 @@ def main():
         # The LAST line printed is the complete one.
         print(line(None, None, True), flush=True)
 
+    if rank == 0 and world == 1 and not a.no_steady:
+        # the contract's K steps are a short region (20 steps = 30 ms): the same loop again in blocks, >= 200 steps in all, for the spread
+        blocks, per = 10, max(20, a.steps)
+        ts = []
+        lanes_mode(n_fl == 1)                                  # (the one-in-flight leg above left engine 0 in lanes mode)
+        with torch.cuda.stream(side):
+            for _ in range(blocks):
+                sync()
+                t0 = time.perf_counter()
+                for _ in range(per):
+                    step()
+                sync()
+                ts.append((time.perf_counter() - t0) / per * 1e3)
+        steady = {"steps": blocks * per, "blocks": blocks, "ms_per_step_mean": round(sum(ts) / len(ts), 4), "ms_per_step_min": round(min(ts), 4),
+                  "ms_per_step_max": round(max(ts), 4), "value_mean": round(B * 1e3 / (sum(ts) / len(ts)), 1)}
+
     roof = None
     if want_roof:
         try:
             # per-op HIP event pairs on the launch stream (eager replay of the same plan), after the timed region
+            hp = eng.head_positions()                     # the last timed forward's winners-only head: positions / winners per level
             eng.set_graph(False)
             prof = eng.profile(frames, iters=5)
-            by_kernel = {}
+            peak_tf = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
+            ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
+            traffic_by_op = op_traffic()
+            if hp is not None:
+                # the head op's algorithmic work from the run's own counters (the plan's figure assumes a third of the winners per level)
+                cin = {int(o["name"].split(".")[3]): o["in"][2] for o in prof if o["name"].startswith("model.23.one2one_cv2.") and o["name"].endswith(".0")}
+                cmid, cout = 64, 64
+                hfl = sum(2.0 * (hp["positions"][l] * 9.0 * cin[l] * cmid + hp["winners"][l] * (9.0 * cmid * cmid + cmid * cout)) for l in range(3))
+                hby = sum(hp["positions"][l] * (9.0 * cin[l] * 2 + 2.0 * cmid * 2) + hp["winners"][l] * cout * 4 + (9.0 * cin[l] * cmid + 9.0 * cmid * cmid + cmid * cout) * 2 for l in range(3))
+                for o in prof:
+                    if o["name"] == "model.23.postprocess":
+                        base_by = sum(q["bytes"] for q in prof if q["name"].startswith("model.23.amax.")) + B * 300 * (80 + 64 + 6 + 1) * 4
+                        o["flops"], o["bytes"] = hfl, hby + base_by
+            layers, by_kernel = [], {}
             for o in prof:
                 if o["kernel"] == "-":       # work done by a fused consumer: no launch of its own
                     continue
-                k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0))
+                sec = o["ms"] * 1e-3
+                ai = o["flops"] / max(o["bytes"], 1.0)
+                bound_tf = min(peak_tf, ai * PEAK_HBM_GBS * 1e-3)              # the north star's definition: min(P, AI x BW), TFLOP/s
+                if o["flops"] > 0:
+                    frac = (o["flops"] / sec / 1e12) / bound_tf
+                else:                                                           # pure data movement (pools, class-max): bytes against HBM
+                    frac = (o["bytes"] / sec / 1e9) / PEAK_HBM_GBS
+                tr = traffic_by_op.get(o["name"])
+                layers.append(dict(op=o["name"], kernel=o["kernel"].split("<")[0], us=round(o["ms"] * 1e3, 2), gflop=round(o["flops"] / 1e9, 3),
+                                   mb=round(o["bytes"] / 1e6, 2), bound="mfma" if ai >= ridge else "hbm", frac=round(frac, 3),
+                                   traffic_mb=None if tr is None else round(tr / 1e6, 2)))
+                k = by_kernel.setdefault(o["kernel"], dict(ms=0.0, flops=0.0, bytes=0.0, n=0, traffic=0, tn=0))
                 k["ms"] += o["ms"]; k["flops"] += o["flops"]; k["bytes"] += o["bytes"]; k["n"] += 1
+                if tr is not None:
+                    k["traffic"] += tr; k["tn"] += 1
             total_ms = sum(k["ms"] for k in by_kernel.values())
+            # whole-step fraction: the time the step would take with every layer AT its bound, over the time it takes
+            bound_ms = sum(max(o["flops"] / (peak_tf * 1e12), o["bytes"] / (PEAK_HBM_GBS * 1e9)) * 1e3 for o in prof if o["kernel"] != "-")
             dom = max(by_kernel, key=lambda n: by_kernel[n]["ms"])      # the single device symbol with the most time
             d = by_kernel[dom]
             ai = d["flops"] / max(d["bytes"], 1.0)
-            peak_tf = PEAK_BF16_TFLOPS if a.dtype == "bf16" else PEAK_F32_TFLOPS
-            ridge = peak_tf * 1e12 / (PEAK_HBM_GBS * 1e9)
             avg_ms = d["ms"] / d["n"]
-            traffic = measured_traffic(dom)
+            traffic = round(d["traffic"] / d["tn"]) if d["tn"] == d["n"] else None      # mean over this symbol's ops, when every one was measured
             if ai >= ridge:
                 ach = d["flops"] / d["n"] / (avg_ms * 1e-3) / 1e12
                 roof = dict(bound="mfma", achieved=round(ach, 2), peak=peak_tf, unit="TFLOP/s", frac=round(ach / peak_tf, 4), traffic=traffic)
@@ -318,29 +368,38 @@ def main():
             # the conv family as a whole (all instantiations of the LDS-DMA MFMA conv kernels), for orientation
             fam = [v for n, v in by_kernel.items() if n.startswith("conv_")]
             fam_ms, fam_fl, fam_by = sum(v["ms"] for v in fam), sum(v["flops"] for v in fam), sum(v["bytes"] for v in fam)
-            roof.update(kernel=dom, launches_per_step=d["n"], avg_launch_ms=round(avg_ms, 5),
+            roof.update(kernel=dom, ops=[o["name"] for o in prof if o["kernel"] == dom], launches_per_step=d["n"], avg_launch_ms=round(avg_ms, 5),
                         alg_bytes_per_launch=round(d["bytes"] / d["n"]), alg_flops_per_launch=round(d["flops"] / d["n"]),
                         flop_per_byte=round(ai, 1), tflops=round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
                         share_of_step=round(d["ms"] / total_ms, 3), eager_step_ms=round(total_ms, 3),
+                        step_frac=round(bound_ms / total_ms, 4),
+                        traffic_source="profiles/op_traffic.json (by op name)" if traffic_by_op else None,
+                        head_positions=hp,
                         conv_family=dict(ms=round(fam_ms, 4), share_of_step=round(fam_ms / total_ms, 3),
                                          tflops=round(fam_fl / max(fam_ms, 1e-9) / 1e9, 1), gbs=round(fam_by / max(fam_ms, 1e-9) / 1e6, 0)),
-                        kernels={n: dict(ms=round(v["ms"], 4), n=v["n"], tflops=round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 1),
-                                         gbs=round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 0)) for n, v in by_kernel.items()})
+                        per_layer=layers)
         except Exception as ex:      # (a failed diagnostic pass must not cost the measured line)
             roof = {"error": f"{type(ex).__name__}: {ex}"}
 
     if rank == 0 and world == 1 and not a.no_dense_head and not a.no_graph and a.dtype == "bf16" and os.environ.get("YOLOP_DENSE_HEAD") != "1":
         # comparison leg, outside the timed region: the same step with the box branch dense over all 8400 anchors (what round 2 measured),
-        # and how far the two engines' detections are apart on these frames
+        # and the check that the winners-only head returns the dense head's detections on the TIMED network and frames. The dense engine
+        # runs the timed engine's tile configurations (bf16 scores depend on the fp32 summation order of the class branch; with its own
+        # autotune the dense engine's top-300 sets differ - that is what BENCH_r03's `false / 610 px` was). A mismatch fails the run.
         try:
+            cfgs = eng.tuning_export()
             os.environ["YOLOP_DENSE_HEAD"] = "1"                # read by yp_create
             try:
                 de = Engine(a.variant, 80, a.seg, a.dtype, local, state=st)
             finally:
                 del os.environ["YOLOP_DENSE_HEAD"]
+            de.tuning_import(B, S, S, cfgs)
             out_d = {k: (torch.empty_like(v) if v is not None else None) for k, v in out.items()}
+            out_w = {k: (torch.empty_like(v) if v is not None else None) for k, v in out.items()}
             de.set_graph(True)
+            eng.set_graph(True)
             with torch.cuda.stream(side):
+                eng.forward(frames, out_w)                      # the timed engine once more, into buffers nothing else writes
                 for _ in range(max(a.warmup, 3)):
                     de.forward(frames, out_d)
                 torch.cuda.synchronize(dev)
@@ -349,12 +408,45 @@ def main():
                     de.forward(frames, out_d)
                 torch.cuda.synchronize(dev)
                 dt_d = time.perf_counter() - t0
+            same = bool(torch.equal(out_w["idx"], out_d["idx"]) and torch.equal(out_w["det"][..., 4:], out_d["det"][..., 4:]))
+            dbox = float((out_w["det"][..., :4] - out_d["det"][..., :4]).abs().max())
+            same_timed = bool(torch.equal(out_w["det"], out["det"]) and torch.equal(out_w["idx"], out["idx"]))   # what the timed steps left in `out`
             head_note["dense_head"] = {"ms_per_step": round(dt_d / a.steps * 1e3, 4), "value": round(B * a.steps / dt_d, 1),
-                                       "same_anchors_classes_scores": bool(torch.equal(out["idx"], out_d["idx"]) and torch.equal(out["det"][..., 4:], out_d["det"][..., 4:])),
-                                       "max_box_difference_px": round(float((out["det"][..., :4] - out_d["det"][..., :4]).abs().max()), 4)}
+                                       "tile_configurations": "imported from the timed engine",
+                                       "same_anchors_classes_scores": same, "max_box_difference_px": round(dbox, 4),
+                                       "timed_steps_left_the_same_detections": same_timed}
+            if not same or dbox > 2.0 or not same_timed:
+                failures.append("winners-only head differs from the dense head on the timed workload")
             de.close()
         except Exception as ex:
             head_note["dense_head"] = {"error": f"{type(ex).__name__}: {ex}"}
+            failures.append("dense-head cross-check did not run")
+
+    if rank == 0 and world == 1 and not a.no_spread and not a.no_graph and a.dtype == "bf16":
+        # the bench network (ultralytics' bias_init: class bias log(5/nc/(640/stride)^2)) puts all 300 winners of a frame on P5, the cheapest
+        # case for the winners-only head (work = min(9 x winners, H x W) positions per level). Same network with EQUAL class biases on the
+        # three levels: winners spread over P3 / P4 / P5 as a trained detector's do. One batch in flight, graph with lanes.
+        try:
+            st2 = synthetic_state(a.variant, 80, a.seg, seed=0, cls_bias=-6.0)
+            e2 = Engine(a.variant, 80, a.seg, a.dtype, local, state=st2)
+            e2.tuning_import(B, S, S, eng.tuning_export())
+            out2 = {k: (torch.empty_like(v) if v is not None else None) for k, v in out.items()}
+            e2.set_graph(True)
+            with torch.cuda.stream(side):
+                for _ in range(max(a.warmup, 3)):
+                    e2.forward(frames, out2)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                for _ in range(a.steps):
+                    e2.forward(frames, out2)
+                torch.cuda.synchronize(dev)
+                dt2 = time.perf_counter() - t0
+            head_note["spread_winners"] = {"ms_per_step": round(dt2 / a.steps * 1e3, 4), "value": round(B * a.steps / dt2, 1), "in_flight": 1,
+                                           "class_bias": "-6.0 on every level", "head": e2.head_positions(),
+                                           "compare_with": "one_in_flight (same mode, the bench network)"}
+            e2.close()
+        except Exception as ex:
+            head_note["spread_winners"] = {"error": f"{type(ex).__name__}: {ex}"}
 
     cpu = None
     if want_cpu:
@@ -372,6 +464,8 @@ def main():
         dist.destroy_process_group()
     for e2 in ring.engines:
         e2.close()
+    if failures:
+        raise SystemExit("bench.py: " + "; ".join(failures) + " (the measured line above stands; this exit status marks the failed cross-check)")
 
 
 if __name__ == "__main__":

@@ -245,12 +245,26 @@ int yp_debug_contour_clocks(uint64_t* out12);
 /* Host-only self-check of the executor for the current plan (parameter blocks, kernel symbols, tune-cache round trip, lane
  * schedule invariants). Needs no GPU; returns the number of scheduled launches or <0. Used by the CPU sanitizer build. */
 int yp_debug_host_selftest(yp_engine* e);
+/* What the last capture built: out[0] captures + instantiations so far, [1] graph nodes, [2] graph edges, [3] edges into the first node
+   of every op as the lane schedule prescribes them (for a chain: nodes - 1; [2] - [3] = the inner chains of ops that launch several
+   kernels), [4] lanes that launched, [5] 1 while an executable exists. */
+int yp_debug_graph_info(const yp_engine* e, int64_t* out6);
+/* Winners-only head, last forward: out[0..3) distinct positions listed per level (P3, P4, P5; all images), out[3..6) winners per level.
+   Returns 0 for a dense head (out zeroed). Synchronises the device. */
+int yp_debug_head_positions(yp_engine* e, int64_t* out6);
+/* Profiling hook: enqueue a one-thread kernel named op_marker_kernel (tools/op_traffic.py brackets the launches of one op with it so that
+   per-dispatch counter rows can be attributed to ops). */
+int yp_debug_marker(void* stream);
 
-/* hipGraph capture + replay of the forward: 0 = eager launches on the caller's stream (the library default), 1 = one hipGraph with
- * concurrent head lanes replayed on the engine's own stream (what bench.py and smoke() use), 2 = graph without lanes (A/B),
+/* hipGraph capture + replay of the forward: 0 = eager launches on the caller's stream (the library default), 1 = one hipGraph whose
+ * independent head branches are parallel branches of the graph, 2 = the graph as one chain (what a ring of several engines uses; A/B),
  * 3 = auto: per input shape, whichever of 0 and 1 a one-off timing inside the first yp_forward of that shape finds faster on this box
  * (what predictor.py uses: one frame per call - yolo_seg/app.py:85-91 - runs eagerly, batches replay). The first forward of every
- * input shape runs once eagerly inside yp_forward before anything is captured. */
+ * input shape runs once eagerly inside yp_forward before anything is captured.
+ * Stream contract: a replay is launched on the CALLER's stream (`stream` of yp_forward); a caller on the legacy NULL stream gets the
+ * engine's own stream ordered in between by an event pair. Forwards of one engine never overlap: a call on another stream than the
+ * engine's previous call first waits (on the device) for that call's completion event. The graph is specialised on the plan, the input
+ * pointer and the output pointers; a caller that keeps them from call to call never re-captures (yp_debug_graph_info counts captures). */
 int yp_set_graph(yp_engine* e, int enable);
 
 #ifdef __cplusplus

@@ -200,3 +200,65 @@ def select_best_box(xyxy: np.ndarray, conf: np.ndarray, last_box, width: int, he
     if last_box is None:
         return (0, 0, width, height), None
     return last_box, None
+
+
+
+# ---- A.7 masks2segments, later 8.3.x form [U] ------------------------------------------------------------------------------------
+# Restated from the published ultralytics sources as recalled (the package is not in /root/reference and not installed: unpinned).
+# ultralytics/utils/ops.py masks2segments(masks, strategy="all"): per mask `c = cv2.findContours(x, RETR_EXTERNAL, CHAIN_APPROX_SIMPLE)[0]`;
+#   "largest": the contour with the most points;   "all", releases up to early 8.3: `np.concatenate([x.reshape(-1, 2) for x in c])`;
+#   "all", later 8.3.x: `np.concatenate(merge_multi_segment([x.reshape(-1, 2) for x in c])) if len(c) > 1 else c[0].reshape(-1, 2)` -
+#   the contours are CONNECTED at their closest points instead of being laid end to end.
+# ultralytics/data/converter.py merge_multi_segment / min_index (the COCO converter's routine) is restated below line by line.
+# Every point of every contour appears in the merged polygon (some twice: a closing point per contour, the bridge points), so the point
+# SET, its convex hull and cv2.minAreaRect - what the reference reads out of `masks.xy[best]` (yolo_seg/app.py:101-103 ->
+# utils/mask_tools.py:12-22) - are the same for both forms; only the polygon's vertex order differs.
+def min_index(arr1: np.ndarray, arr2: np.ndarray) -> Tuple[int, int]:
+    dis = ((arr1[:, None, :] - arr2[None, :, :]) ** 2).sum(-1)
+    i = int(np.argmin(dis, axis=None))                      # first minimum in row-major order
+    return i // dis.shape[1], i % dis.shape[1]
+
+
+def merge_multi_segment(segments: Sequence[np.ndarray]) -> list:
+    s = []
+    segments = [np.array(i).reshape(-1, 2) for i in segments]
+    idx_list = [[] for _ in range(len(segments))]
+    for i in range(1, len(segments)):                       # closest pair of points between consecutive contours
+        idx1, idx2 = min_index(segments[i - 1], segments[i])
+        idx_list[i - 1].append(idx1)
+        idx_list[i].append(idx2)
+    for k in range(2):                                      # forward pass, then the way back over the middle contours
+        if k == 0:
+            for i, idx in enumerate(idx_list):
+                if len(idx) == 2 and idx[0] > idx[1]:       # a middle contour is walked from its entry point to its exit point
+                    idx = idx[::-1]
+                    segments[i] = segments[i][::-1, :]
+                segments[i] = np.roll(segments[i], -idx[0], axis=0)
+                segments[i] = np.concatenate([segments[i], segments[i][:1]])
+                if i in {0, len(idx_list) - 1}:             # first and last contour: whole, closed
+                    s.append(segments[i])
+                else:
+                    idx = [0, idx[1] - idx[0]]
+                    s.append(segments[i][idx[0]: idx[1] + 1])
+        else:
+            for i in range(len(idx_list) - 1, -1, -1):
+                if i not in {0, len(idx_list) - 1}:
+                    idx = idx_list[i]
+                    nidx = abs(idx[1] - idx[0])
+                    s.append(segments[i][nidx:])
+    return s
+
+
+def masks2segments_contours(contours: Sequence[np.ndarray], strategy: str = "all", merged: bool = True) -> np.ndarray:
+    """masks2segments [U] applied to the contour list cv2.findContours would return for one mask (list order = cv2's: last found first).
+    merged=True: the later 8.3.x "all" (merge_multi_segment); merged=False: plain concatenation (earlier releases)."""
+    c = [np.asarray(x).reshape(-1, 2) for x in contours]
+    if not c:
+        return np.zeros((0, 2), dtype=np.float32)
+    if strategy == "all":
+        out = (np.concatenate(merge_multi_segment(c)) if merged else np.concatenate(c)) if len(c) > 1 else c[0]
+    elif strategy == "largest":
+        out = c[int(np.array([len(x) for x in c]).argmax())]
+    else:
+        raise ValueError(strategy)
+    return out.astype(np.float32)

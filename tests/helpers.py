@@ -166,15 +166,23 @@ def make_case_family(family: str, variant: str = "n", nc: int = 80, seed: int = 
 NOISE_FACTOR = 2.0
 
 
-def assert_within_noise_floor(what: str, eng: torch.Tensor, o32: torch.Tensor, o64: torch.Tensor, target: float, factor: float = NOISE_FACTOR) -> float:
+def assert_within_noise_floor(what: str, eng: torch.Tensor, o32: torch.Tensor, o64: torch.Tensor, target: float, factor: float = NOISE_FACTOR,
+                              ceiling: float = None) -> float:
     """The reference's CPU path is an fp32 program: run in fp64 (the oracle's `fp64` mode) the same network gives the exact answer up to
     1e-12, and |oracle_fp32 - oracle_fp64| is the error the reference's OWN arithmetic makes on this input - its noise floor. An fp32
     engine that sums in another order is a second sample of that noise; the contract is
-        max |engine_fp32 - oracle_fp64|  <=  factor * max |oracle_fp32 - oracle_fp64|        (factor = 2)
-    on the same elements. `target` is north_star's absolute figure (1e-3 on box / mask floats): printed next to the two measured numbers,
-    not asserted - on these synthetic networks the reference's own floor is already of that size. Returns the engine's error."""
-    e = float((eng.double() - o64.double()).abs().max()) if eng.numel() else 0.0
-    f = float((o32.double() - o64.double()).abs().max()) if eng.numel() else 0.0
-    print(f"[noise floor] {what}: engine_fp32 vs oracle_fp64 {e:.3e}; oracle_fp32 vs oracle_fp64 {f:.3e} (x{e / max(f, 1e-30):.2f}); north_star target {target:g}")
-    assert e <= factor * f, (what, e, f)
+        max |engine_fp32 - oracle_fp64|  <=  min(factor * max |oracle_fp32 - oracle_fp64|, ceiling)        (factor = 2, ceiling = 5 * target)
+    on the same elements, which must exist (an empty selection proves nothing). `target` is north_star's absolute figure (1e-3 on box /
+    mask floats): printed next to the two measured numbers; the absolute `ceiling` keeps a case whose oracle is itself noisy
+    (near-cancelling synthetic weights) from passing an arbitrarily large engine error. Returns the engine's error."""
+    assert eng.numel() > 0, f"{what}: empty selection - nothing was compared"
+    if ceiling is None:
+        ceiling = 5.0 * target
+    e = float((eng.double() - o64.double()).abs().max())
+    f = float((o32.double() - o64.double()).abs().max())
+    tiny = 1e-7 * max(float(o64.double().abs().max()), 1e-30)          # (an exact oracle pair, f = 0: the engine may still round once)
+    bound = min(max(factor * f, tiny), ceiling)
+    print(f"[noise floor] {what}: engine_fp32 vs oracle_fp64 {e:.3e}; oracle_fp32 vs oracle_fp64 {f:.3e} (x{e / max(f, 1e-30):.2f}); "
+          f"asserted bound {bound:.3e} (ceiling {ceiling:g}); north_star target {target:g}; {eng.numel()} values")
+    assert e <= bound, (what, e, f, bound)
     return e

@@ -1,13 +1,16 @@
-"""yp_mask_contours (HIP: bit image in LDS, parallel Moore traces, RETR_EXTERNAL by crossing parity, hull, rotating calipers) against the
-host statement of what the reference does with a mask per frame (yolo_seg/app.py:101-103: masks.xy[best] -> get_coord_min_rect_len):
-hostops.mask_polygon = connected components + hole filling + a reversed Moore trace, itself held to a Suzuki & Abe restatement in
-tests/test_host.py. The polygon is integer work and must be identical point for point, in both masks2segments strategies; the rectangle
-is float64 and is also checked against an independent brute-force form."""
+"""yp_mask_contours (HIP: bit image in LDS, parallel Moore traces, RETR_EXTERNAL by crossing parity, hull, rotating calipers) against
+what the reference does with a mask per frame (yolo_seg/app.py:101-103: masks.xy[best] -> get_coord_min_rect_len; utils/mask_tools.py:12-22).
+The CHECKER is test infrastructure only: tests/suzuki_abe.py (Suzuki & Abe's border following as cv2.findContours(RETR_EXTERNAL,
+CHAIN_APPROX_SIMPLE) runs it) for the polygon, scipy's qhull + explicit rotation of all points for the rectangle - neither shares code
+with the product. The product's own host statement (hostops.mask_polygon, the fallback Masks.xy takes when the kernel declines) is held
+to the same outputs as a second assertion. The polygon is integer work and must be identical point for point, in both masks2segments
+strategies; the rectangle is float64."""
 import numpy as np
 import pytest
 import torch
 
 from helpers import rand_image
+from suzuki_abe import find_contours_external_simple
 from yolo_puncture_amd import hostops
 from yolo_puncture_amd.engine import mask_contours_device
 
@@ -123,12 +126,23 @@ def _more_cases():
 ALL = _cases() + _more_cases()
 
 
+def _oracle_polygon(mask, strategy):
+    """masks2segments [U] on the test-side contour statement: every external contour bottom-up ("all": concatenated; "largest": the one
+    with the most points, the first of the list on a tie) -> (int32 [m,2], contour lengths)."""
+    cs = find_contours_external_simple(mask.astype(bool))
+    if not cs:
+        return np.zeros((0, 2), np.int32), []
+    if strategy == "all":
+        return np.concatenate(cs).astype(np.int32), [len(c) for c in cs]
+    best = max(range(len(cs)), key=lambda i: (len(cs[i]), -i))
+    return cs[best].astype(np.int32), [len(cs[best])]
+
+
 @pytest.mark.parametrize("strategy", ["all", "largest"])
 @pytest.mark.parametrize("name,mask", ALL, ids=[n for n, _ in ALL])
 def test_contour_and_rect_match_host(name, mask, strategy):
     polys, rect, parts = mask_contours_device(torch.from_numpy(mask)[None].cuda(), max_pts=8192, strategy=strategy, want_parts=True)
-    want = hostops.mask_polygon(mask.astype(bool), strategy)
-    ext = hostops.external_contours(mask.astype(bool))
+    want, want_parts = _oracle_polygon(mask, strategy)                    # test-side statement (tests/suzuki_abe.py)
     got = polys[0]
     if name in ("dots", "many_dots_nested") and strategy == "all":      # hundreds of isolated pixels: more outer borders than the device lists (64) -> declined, not wrong
         assert got is None
@@ -136,15 +150,49 @@ def test_contour_and_rect_match_host(name, mask, strategy):
     assert got is not None, "the device path must handle this mask"
     assert got.dtype == np.int32 and got.shape == want.shape, (got.shape, want.shape)
     assert np.array_equal(got, want)                                       # integer work: identical, point for point, same order
-    if strategy == "all":
-        assert parts[0] == [len(c) for c in ext]                            # the list's contours, bottom-up
-    else:
-        assert parts[0] == ([len(want)] if len(want) else [])
-    wl, ww = hostops.min_area_rect_size(want) if want.shape[0] else (0.0, 0.0)
-    assert rect[0, 0] == pytest.approx(wl, rel=1e-12, abs=1e-12) and rect[0, 1] == pytest.approx(ww, rel=1e-12, abs=1e-9)
-    if want.shape[0] >= 3:
+    assert parts[0] == want_parts                                          # the list's contours, bottom-up
+    if want.shape[0] >= 3:                                                 # rectangle: qhull + rotation of all points (no product code)
         bl, bw = _brute_min_rect(want)
         assert rect[0, 0] == pytest.approx(bl, rel=1e-9, abs=1e-9) and rect[0, 1] == pytest.approx(bw, rel=1e-9, abs=1e-7)
+    elif want.shape[0] == 2:
+        assert rect[0, 0] == pytest.approx(float(np.hypot(*(want[1] - want[0]).astype(np.float64))), abs=1e-12) and rect[0, 1] == pytest.approx(0.0, abs=1e-12)
+    else:
+        assert rect[0, 0] == 0.0 and rect[0, 1] == 0.0
+    # second assertion: the product's host statement (the fallback path of Masks.xy) says the same
+    host = hostops.mask_polygon(mask.astype(bool), strategy)
+    assert np.array_equal(got, host)
+    wl, ww = hostops.min_area_rect_size(host) if host.shape[0] else (0.0, 0.0)
+    assert rect[0, 0] == pytest.approx(wl, rel=1e-12, abs=1e-12) and rect[0, 1] == pytest.approx(ww, rel=1e-12, abs=1e-9)
+
+
+def test_random_masks_against_suzuki_abe():
+    """A few hundred random masks of every density (nested blobs, one-pixel rings, diagonal links) in ONE batched device call per strategy,
+    each held to tests/suzuki_abe.py + the brute-force rectangle."""
+    rng = np.random.default_rng(11)
+    H, W, N = 24, 40, 320
+    ms = np.zeros((N, H, W), np.uint8)
+    for i in range(N):
+        h, w = int(rng.integers(3, H + 1)), int(rng.integers(3, W + 1))
+        m = rng.random((h, w)) < rng.choice([0.15, 0.35, 0.5, 0.65, 0.8])
+        if i % 5 == 0 and h >= 9 and w >= 9:
+            m[:] = False
+            m[1:h - 1, 1:w - 1] = True
+            m[2 + i % 2:h - 2, 2:w - 2 - i % 3] = rng.random((h - 4 - i % 2, w - 4 - i % 3)) < 0.3
+        ms[i, :h, :w] = m
+    for strategy in ("all", "largest"):
+        polys, rect = mask_contours_device(torch.from_numpy(ms).cuda(), strategy=strategy)
+        declined = 0
+        for i in range(N):
+            want, _ = _oracle_polygon(ms[i], strategy)
+            if polys[i] is None:                       # (more than 64 outer borders in "all": declined, the host path takes over)
+                declined += 1
+                assert strategy == "all" and len(find_contours_external_simple(ms[i].astype(bool))) > 64
+                continue
+            assert np.array_equal(polys[i], want), (i, strategy)
+            if want.shape[0] >= 3:
+                bl, bw = _brute_min_rect(want)
+                assert rect[i, 0] == pytest.approx(bl, rel=1e-9, abs=1e-9) and rect[i, 1] == pytest.approx(bw, rel=1e-9, abs=1e-7), (i, strategy)
+        assert declined < N // 10
 
 
 def test_nested_blob_is_not_external():
@@ -171,8 +219,9 @@ def test_noise_mask_one_lane_path():
     m = (rng.random((200, 300)) < 0.5).astype(np.uint8)
     m[40:160, 60:240] = 1; m[60:140, 90:210] = 0; m[80:120, 120:180] = (rng.random((40, 60)) < 0.62)     # a noisy blob inside a ring inside noise
     polys, rect = mask_contours_device(torch.from_numpy(m)[None].cuda(), strategy="largest")
-    want = hostops.mask_polygon(m.astype(bool), "largest")
+    want = _oracle_polygon(m, "largest")[0]
     assert polys[0] is not None and np.array_equal(polys[0], want)
+    assert np.array_equal(want, hostops.mask_polygon(m.astype(bool), "largest"))
     polys, _ = mask_contours_device(torch.from_numpy(m)[None].cuda(), strategy="all")
     assert polys[0] is None
 
@@ -181,10 +230,10 @@ def test_batch_of_masks_and_fallback_codes():
     ms = np.stack([_blobs(120, 160, s) for s in range(5)] + [np.zeros((120, 160), np.uint8)])
     polys, rect = mask_contours_device(torch.from_numpy(ms).cuda())
     for i in range(6):
-        assert np.array_equal(polys[i], hostops.mask_polygon(ms[i].astype(bool), "all"))
+        assert np.array_equal(polys[i], _oracle_polygon(ms[i], "all")[0])
     polys_l, _ = mask_contours_device(torch.from_numpy(ms).cuda(), strategy="largest")
     for i in range(6):
-        assert np.array_equal(polys_l[i], hostops.largest_external_contour(ms[i].astype(bool)))
+        assert np.array_equal(polys_l[i], _oracle_polygon(ms[i], "largest")[0])
     assert polys[5].shape == (0, 2) and rect[5, 0] == 0.0
     # too many points for the caller's buffer -> the device pass declines (host path takes over in Masks.xy)
     polys, _ = mask_contours_device(torch.from_numpy((np.indices((64, 80)).sum(0) % 2).astype(np.uint8))[None].cuda(), max_pts=16)
@@ -228,6 +277,25 @@ def test_hole_border_with_local_tops_is_not_a_contour():
     m2[24:28, 44:76:4] = 1                     # ... with spikes of its own (outer-border local tops of the nested blob)
     polys, rect = mask_contours_device(torch.from_numpy(np.stack([m, m2])).cuda(), strategy="largest")
     for i, mm in enumerate((m, m2)):
-        want = hostops.largest_external_contour(mm.astype(bool))
+        want = _oracle_polygon(mm, "largest")[0]
         assert polys[i] is not None and np.array_equal(polys[i], want), (i, len(polys[i]), len(want))
     assert len(polys[0]) == 4
+
+
+def test_masks_xy_all_merged_strategy():
+    """MASK_POLYGON_STRATEGY = "all_merged" (masks2segments of the later 8.3.x releases [U]): contours from the device, bridged on the host,
+    against the oracle's restatement of merge_multi_segment on the test-side contours; the rectangle is the one "all" gives."""
+    from oracle import postprocess_oracle as po
+    from yolo_puncture_amd.predictor import Masks
+    ms = np.stack([_blobs(120, 160, s, thr=0.62) for s in range(4)] + [ALL[[n for n, _ in ALL].index("fragmented_bar")][1][:120, :160]])
+    dev = Masks(torch.from_numpy(ms).cuda().float(), (120, 160), u8=torch.from_numpy(ms).cuda(), strategy="all_merged")
+    plain = Masks(torch.from_numpy(ms).cuda().float(), (120, 160), u8=torch.from_numpy(ms).cuda(), strategy="all")
+    multi = 0
+    for i in range(len(ms)):
+        cs = find_contours_external_simple(ms[i].astype(bool))
+        want = po.masks2segments_contours(cs, "all", merged=True)
+        assert np.array_equal(dev.xy[i], want), i
+        multi += len(cs) > 1
+        if len(plain.xy[i]) >= 3:
+            assert dev.min_rect_len(i) == plain.min_rect_len(i)
+    assert multi >= 2

@@ -50,7 +50,7 @@ def _soften(st):
     return st
 
 
-def _check_head_against_oracle(eng, orc, out, B, H, W, nc):
+def _check_head_against_oracle(eng, orc, out, B, H, W, nc, min_gap_frac=0.6):
     bl, cl = _logits(eng, B, H, W, nc)
     shapes = [(H // s, W // s) for s in (8, 16, 32)]
     boxes, scores = orc.decode(bl, cl, shapes)
@@ -61,7 +61,8 @@ def _check_head_against_oracle(eng, orc, out, B, H, W, nc):
     gap_ok = torch.ones_like(want[..., 4], dtype=torch.bool)
     gap_ok[:, :-1] &= (want[:, :-1, 4] - want[:, 1:, 4]) > 1e-6                       # rows that are not float near-ties
     gap_ok[:, 1:] &= (want[:, :-1, 4] - want[:, 1:, 4]) > 1e-6
-    assert gap_ok.float().mean() > 0.6                                                # the data must pose an ordering problem
+    print(f"rows with a clear score gap: {float(gap_ok.float().mean()):.3f}")
+    assert gap_ok.float().mean() > min_gap_frac                                       # the data must pose an ordering problem
     assert torch.equal(idx[:, :k][gap_ok], widx[gap_ok])                              # integer work: bit-exact
     assert torch.equal(det[:, :k, 5][gap_ok], want[..., 5][gap_ok])
     assert float((det[:, :k, :4] - want[..., :4])[gap_ok].abs().max()) < 1e-3        # px, north_star's float bound
@@ -224,7 +225,57 @@ def test_config_1_v10n_one_frame_end_to_end(tmp_path):
     assert same.float().mean() > 0.9
     # floats within 2 x the reference's own fp32 noise floor on this frame (helpers.assert_within_noise_floor; target 1e-3 printed)
     assert_within_noise_floor("config 1 boxes [px, original frame]", torch.from_numpy(b.xyxy)[same], det[:, :4][same], det64[:, :4][same], 1e-3)
-    assert_within_noise_floor("config 1 conf", torch.from_numpy(b.conf)[same], det[:, 4][same], det64[:, 4][same], 1e-3)
+    assert_within_noise_floor("config 1 conf", torch.from_numpy(b.conf)[same], det[:, 4][same], det64[:, 4][same], 1e-3, ceiling=1e-4)
     assert r.masks is None
     xywhn = b.xywhn                                                       # cls_bbox_dataset_generate.py:52
     assert xywhn.shape == (len(b.cls), 4) and float(xywhn.min()) >= 0.0 and float(xywhn.max()) <= 1.0
+
+
+
+def test_bench_workload_exact():
+    """EXACTLY what bench.py times: `synthetic_state("s", 80, False, seed=0)` - un-calibrated, ultralytics' bias_init -
+    and `torch.randint` frames seed 0, 32 x 640 x 640, hipGraph replay. (i) the winners-only head against the dense head of a second engine
+    that runs the SAME tile configurations: anchors, classes and scores bit-identical, boxes within 2 px; (ii) the oracle's head on the
+    engine's fp32 logits for the whole batch; (iii) the oracle's trunk on frames {0, 15, 31}; (iv) replay = eager, bit for bit."""
+    import os
+    from yolo_puncture_amd.engine import Engine
+    B, S = 32, 640
+    st = synthetic_state("s", 80, False, seed=0)
+    g = torch.Generator().manual_seed(0)
+    im = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8, generator=g).cuda()
+    eng = Engine("s", 80, False, "bf16", 0, state=st)
+    out = {k: v.clone() for k, v in eng.forward(im).items() if v is not None}            # eager
+    torch.cuda.synchronize()
+    hp = eng.head_positions()
+    assert hp is not None, "the bench workload is expected to run the winners-only head"
+    print("winners-only head:", hp)
+    assert sum(hp["winners"]) == B * 300
+    orc = Oracle(st, "s", 80, False, "fp32")
+    _check_head_against_oracle(eng, orc, out, B, S, S, 80, min_gap_frac=0.05)
+    _check_trunk_against_oracle(eng, st, "s", False, im, [0, 15, 31])
+    cfgs = eng.tuning_export()
+    eng.set_graph(True)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            rep = eng.forward(im)
+    torch.cuda.synchronize()
+    assert torch.equal(rep["det"], out["det"]) and torch.equal(rep["idx"], out["idx"]), "replay differs from eager launches"
+    os.environ["YOLOP_DENSE_HEAD"] = "1"
+    try:
+        de = Engine("s", 80, False, "bf16", 0, state=st)
+    finally:
+        del os.environ["YOLOP_DENSE_HEAD"]
+    de.tuning_import(B, S, S, cfgs)
+    de.set_graph(True)
+    with torch.cuda.stream(side):
+        dn = de.forward(im)
+    torch.cuda.synchronize()
+    assert de.head_positions() is None
+    assert torch.equal(dn["idx"], out["idx"]), "winners-only and dense head pick different anchors with identical tile configurations"
+    assert torch.equal(dn["det"][..., 4:], out["det"][..., 4:])
+    dbox = float((dn["det"][..., :4] - out["det"][..., :4]).abs().max())
+    print(f"winners-only vs dense head on the bench workload: max box difference {dbox:.4f} px")
+    assert dbox < 2.0
+    de.close()
+    eng.close()

@@ -250,10 +250,10 @@ def test_end_to_end_fp32(variant, seg, shape, nc):
     assert same.float().mean() > 0.9, float(same.float().mean())
     det = res["det"][:, :k]
     assert_within_noise_floor("boxes [px]", det[..., :4][same], ref["det"][..., :4][same], ref64["det"][..., :4][same], 1e-3)
-    assert_within_noise_floor("scores", det[..., 4][same], ref["det"][..., 4][same], ref64["det"][..., 4][same], 1e-3)
+    assert_within_noise_floor("scores", det[..., 4][same], ref["det"][..., 4][same], ref64["det"][..., 4][same], 1e-3, ceiling=1e-4)
     if seg:
         assert_within_noise_floor("mask coefficients", res["coeff"][:, :k][same], ref["coeff"][same], ref64["coeff"][same], 1e-3)
-        assert_within_noise_floor("prototypes", res["proto"], nchw_to_nhwc(ref["proto"]), nchw_to_nhwc(ref64["proto"]), 1e-3)
+        assert_within_noise_floor("prototypes", res["proto"], nchw_to_nhwc(ref["proto"]), nchw_to_nhwc(ref64["proto"]), 1e-3, ceiling=1e-3)
 
 
 @pytest.mark.parametrize("variant,seg,shape,dense", [("n", True, (2, 96, 128), True), ("s", False, (2, 320, 320), True),

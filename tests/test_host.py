@@ -226,3 +226,33 @@ def test_min_area_rect_len():
     length, ratio = hostops.get_coord_min_rect_len(cloud)
     bw, bh = np.ptp(cloud[:, 0]), np.ptp(cloud[:, 1])
     assert length * (length / ratio) <= bw * bh + 1e-6
+
+
+def test_masks2segments_merged_form_of_later_8_3_x():
+    """`masks2segments(strategy="all")` of the later 8.3.x releases bridges the contours with merge_multi_segment [U]
+    (oracle/postprocess_oracle.py restates it line by line); hostops.merge_contours is the product's form. Same vertices in the same order;
+    and - what the reference actually consumes, yolo_seg/app.py:101-103 - the same point set, hence the same minimum-area rectangle as the
+    plain concatenation."""
+    from oracle import postprocess_oracle as po
+    from suzuki_abe import find_contours_external_simple
+    rng = np.random.default_rng(5)
+    multi = 0
+    for it in range(300):
+        H, W = int(rng.integers(4, 20)), int(rng.integers(4, 24))
+        m = rng.random((H, W)) < rng.choice([0.1, 0.25, 0.4, 0.6])
+        cs = find_contours_external_simple(m)
+        want = po.masks2segments_contours(cs, "all", merged=True)
+        got = hostops.mask_polygon(m, "all_merged")
+        assert got.dtype == np.int32 and np.array_equal(got.astype(np.float32), want), (it, m.astype(int))
+        plain = hostops.mask_polygon(m, "all")
+        assert np.array_equal(plain.astype(np.float32), po.masks2segments_contours(cs, "all", merged=False))
+        assert np.array_equal(hostops.mask_polygon(m, "largest").astype(np.float32), po.masks2segments_contours(cs, "largest"))
+        if len(cs) > 1:
+            multi += 1
+            assert {tuple(p) for p in got.tolist()} == {tuple(p) for p in plain.tolist()}
+            assert hostops.min_area_rect_size(got) == hostops.min_area_rect_size(plain)
+            if len(plain) >= 3:      # (the reference returns (0, 0) below three VERTICES, duplicates counted: utils/mask_tools.py:15-16)
+                assert hostops.get_coord_min_rect_len(got.astype(np.float32)) == hostops.get_coord_min_rect_len(plain.astype(np.float32))
+        else:
+            assert np.array_equal(got, plain)
+    assert multi > 100

@@ -67,13 +67,14 @@ struct yp_engine {
     void* sp_ws = nullptr; size_t sp_ws_bytes = 0;   // winners-only head: sel / wlist / wcount / thr / box rows / coefficient rows
     bool tune = true;             // plan-time autotuning of the conv tile configuration
     hipStream_t own_stream = nullptr;
-    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    hipEvent_t ev_in = nullptr;                      // orders the own-stream replay behind a caller on the legacy NULL stream (forward_replay)
     hipGraphExec_t gexec = nullptr;
-    hipGraph_t gsrc = nullptr;                       // the captured graph gexec was instantiated from: kept alive as long as the executable (see drop_graph)
-    std::vector<hipStream_t> lane_streams;   // [0] unused (lane 0 = own_stream)
-    std::vector<hipEvent_t> lane_events;     // [op] "op done" ; [n + lane] join of a side lane ; [n + nl + lane] fork into a side lane
+    hipGraph_t gsrc = nullptr;                       // the captured graph gexec was instantiated from (kept for yp_debug_graph_info; destroyed with it)
     bool use_lanes = true;
-    // lane schedule of the current plan (pure host data, build_lane_schedule): what run_all_lanes replays
+    int n_captures = 0;                              // captures + instantiations so far (yp_debug_graph_info: a steady-state caller must not add to it)
+    int g_nodes = 0, g_edges = 0, g_edges_expected = 0;
+    hipStream_t last_stream = nullptr; bool have_last = false;   // the stream the previous forward of this engine was enqueued on
+    // lane schedule of the current plan (pure host data, build_lane_schedule): what capture_dag turns into graph edges
     struct LaneStep { int op = -1; std::vector<int> waits; bool fork = false; bool record = false; };
     std::vector<LaneStep> lane_steps;
     std::vector<int> lanes_used;             // side lanes that launch at least one op under this plan (only these join lane 0)
@@ -668,10 +669,8 @@ static int finish_graph_passes(yp_engine& e) {
 // plan: resolve shapes for (B,H,W), compute algorithmic flops/bytes
 // ---------------------------------------------------------------------------------------------------------
 static ConvParams conv_params(const yp_engine& e, const Op& o);
-// Releases the replay executable together with the graph it was instantiated from. The source graph is NOT destroyed right after
-// hipGraphInstantiate: under ROCm 7.2 a forward that replays a re-captured multi-lane graph died with a host SIGSEGV in one full test run
-// out of three (tests/test_gpu_fullsize.py, not reproducible alone; the deterministic variant of it on the NULL stream is described at
-// forward_replay). Sharing the lifetime is a precaution against the executable referring to the source's nodes - not an established cause.
+// Releases the replay executable and the graph it was instantiated from. Callers have made sure no replay of it is in flight
+// (ev_done synchronised, or a device synchronisation): see the lifetime rule at forward_replay.
 static void drop_graph(yp_engine& e) {
     if (e.gexec) { (void)hipGraphExecDestroy(e.gexec); e.gexec = nullptr; }
     if (e.gsrc) { (void)hipGraphDestroy(e.gsrc); e.gsrc = nullptr; }
@@ -695,7 +694,7 @@ static SparseWs sparse_ws_layout(int B, int max_det, const int (&HWl)[3]) {
     auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
     w.sel = take((size_t)B * HEAD_MAXK * 4); w.wlist = take((size_t)B * 3 * HEAD_MAXK * 4); w.wcount = take((size_t)B * 3 * 4); w.thr = take((size_t)B * 4);
     w.box = take((size_t)B * max_det * 64 * 4); w.cf = take((size_t)B * max_det * 32 * 4);
-    w.pcount = take(3 * 4);
+    w.pcount = take(8 * 4);                  // [0..3) live counters, [4..7) the counts of the last forward (head stage 2 saves them)
     size_t ents = 0, rows = 0;
     for (int l = 0; l < 3; ++l) {
         w.plist_off[l] = (int)ents; w.plist_cap[l] = B * std::min(HWl[l], 9 * max_det);   // a winner's 3x3 neighbourhood, never more than the level has
@@ -883,7 +882,23 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         for (int which = 0; which < 2; ++which) {
             const HeadBranchParams q = head_branch_params(e, o, which);
             if (q.cmid == 0 || !head_branch_valid(q)) continue;
-            // the branch's intermediate tensors must have no reader outside the branch (they are never written in this mode)
+            if (which == 1 && !o.sparse_box) continue;              // (stage 2 reads the coefficient rows by rank only beside winners-only box rows)
+            // the branch's tensors must have no reader outside the branch and the head op (they are never written in this mode)
+            bool outside = false;
+            for (int l = 0; l < 3 && !outside; ++l)
+                for (int j = 0; j < 3 && !outside; ++j) {
+                    const int oi = (which == 0 ? o.hb_box : o.hb_cf)[l][j];
+                    const View& w = e.ops[oi].out;
+                    for (size_t r = 0; r < e.ops.size() && !outside; ++r) {
+                        const Op& q2 = e.ops[r];
+                        if (&q2 == &o) continue;
+                        bool member = false;
+                        for (int l2 = 0; l2 < 3; ++l2) for (int j2 = 0; j2 < 3; ++j2) member |= (int)r == (which == 0 ? o.hb_box : o.hb_cf)[l2][j2];
+                        if (member) continue;
+                        for (const View* v : {&q2.in, &q2.res}) outside |= v->t >= 0 && v->t == w.t && v->coff < w.coff + w.C && w.coff < v->coff + v->C;
+                    }
+                }
+            if (outside) continue;
             (which == 0 ? o.sparse_box : o.sparse_cf) = true;
             for (int l = 0; l < 3; ++l)
                 for (int j = 0; j < 3; ++j) {
@@ -1576,47 +1591,78 @@ static int build_lane_schedule(yp_engine& e) {
     return YP_OK;
 }
 
-// Streams and events of the lanes. Created ahead of any capture (prepare): nothing is created, loaded or configured while a
-// stream is capturing.
-static int ensure_lane_resources(yp_engine& e) {
-    const size_t n = e.ops.size();
-    while ((int)e.lane_streams.size() < e.n_lanes) {
-        hipStream_t s;
-        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        e.lane_streams.push_back(s);
-    }
-    while (e.lane_events.size() < n + 2 * (size_t)e.n_lanes) {
-        hipEvent_t ev;
-        HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        e.lane_events.push_back(ev);
-    }
-    return YP_OK;
-}
-
-static int run_all_lanes(yp_engine& e, const RunArgs& a) {
+// Capture of the multi-lane forward as a DAG, on ONE stream and without a single event.
+//
+// Rounds 1-3 captured the lanes as streams: a cross-lane dependency was hipEventRecord on the producer's stream + hipStreamWaitEvent on the
+// consumer's, with one set of events kept for the engine's life and re-used by every capture. A replay of a RE-captured graph of that
+// kind died with a host SIGSEGV inside hipGraphLaunch (tests/test_gpu_fullsize.py: always with the caller on the legacy NULL stream, one
+// run in three otherwise). What those records have in common is the second capture: an event that was recorded inside capture #1 still
+// carries capture #1's state (the graph nodes "in front of" the record) when capture #2 begins, and whenever a record inside capture #2
+// finds nothing new to attach (a fork recorded before the first node of its stream, a lane that launched nothing) the wait that follows
+// takes the STALE node pointers of the destroyed graph #1 as dependencies. Nothing in HIP's interface lets a caller clear an event's
+// capture state, so the rule here is structural:
+//   RULE: no event and no second stream ever takes part in a capture. The op list is captured on own_stream alone; before each op the
+//   stream's dependency set is REPLACED (hipStreamUpdateCaptureDependencies, hipStreamSetCaptureDependencies) by the graph nodes the lane
+//   schedule names - the tail of the op's own lane and the tails of the ops it waits for - and after the op the new tail is read back
+//   (hipStreamGetCaptureInfo_v2). Node handles belong to the graph under construction and die with it; nothing outlives a capture.
+// The resulting graph has the same edges the stream form produced (yp_debug_graph_info reports nodes / edges against the schedule's count).
+// The walk both capture_dag and the host selftest use: `launch(step, deps, tail)` gets the dependency set of the step (sorted, unique) and
+// returns the tail its launches leave behind; `finish(all_tails)` gets the union of the lanes' tails.
+template <class Node, class Launch, class Finish>
+static int walk_lane_dag(const yp_engine& e, Launch launch, Finish finish, int* edges_out) {
     const size_t n = e.ops.size();
     const int nl = e.n_lanes;
-    if ((int)e.lane_streams.size() < nl || e.lane_events.size() < n + 2 * (size_t)nl) return fail(YP_ERR_STATE, "internal: lane resources missing");
-    auto stream_of = [&](int lane) { return lane == 0 ? e.own_stream : e.lane_streams[lane]; };
+    std::vector<std::vector<Node>> lane_tail(nl), op_tail(n);
+    std::vector<char> started(nl, 0);
+    int edges = 0;
     for (const yp_engine::LaneStep& stp : e.lane_steps) {
         const Op& o = e.ops[stp.op];
-        if (stp.fork) {
-            HIPCHK(hipEventRecord(e.lane_events[n + nl + o.lane], e.own_stream));
-            HIPCHK(hipStreamWaitEvent(stream_of(o.lane), e.lane_events[n + nl + o.lane], 0));
-        }
-        for (int j : stp.waits) HIPCHK(hipStreamWaitEvent(stream_of(o.lane), e.lane_events[j], 0));
-        hipError_t err = run_op(e, o, a, stream_of(o.lane));
+        std::vector<Node> deps;
+        if (started[o.lane]) deps = lane_tail[o.lane];
+        else if (stp.fork) deps = lane_tail[0];                       // a side lane whose first op depends on nothing: behind lane 0 as it stands
+        for (int j : stp.waits) deps.insert(deps.end(), op_tail[j].begin(), op_tail[j].end());
+        std::sort(deps.begin(), deps.end());
+        deps.erase(std::unique(deps.begin(), deps.end()), deps.end());
+        int rc = launch(stp, deps, lane_tail[o.lane]);
+        if (rc != YP_OK) return rc;
+        started[o.lane] = 1;
+        if (stp.record) op_tail[stp.op] = lane_tail[o.lane];
+        edges += (int)deps.size();
+    }
+    std::vector<Node> all;
+    for (int l = 0; l < nl; ++l) if (started[l]) all.insert(all.end(), lane_tail[l].begin(), lane_tail[l].end());
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    if (edges_out) *edges_out = edges;                                // edges INTO the first node of every op (an op of several kernels adds its inner chain)
+    return finish(all);
+}
+
+static int capture_dag(yp_engine& e, const RunArgs& a) {
+    hipStream_t cs = e.own_stream;
+    bool first = true;
+    auto launch = [&](const yp_engine::LaneStep& stp, std::vector<hipGraphNode_t>& deps, std::vector<hipGraphNode_t>& tail) -> int {
+        const Op& o = e.ops[stp.op];
+        // (the very first op starts from the empty set a fresh capture has)
+        if (!first) HIPCHK(hipStreamUpdateCaptureDependencies(cs, deps.empty() ? nullptr : deps.data(), deps.size(), hipStreamSetCaptureDependencies));
+        first = false;
+        hipError_t err = run_op(e, o, a, cs);
         if (err != hipSuccess) return fail(YP_ERR_HIP, "launch of op '%s' failed: %s", o.name.c_str(), hipGetErrorString(err));
-        if (stp.record) HIPCHK(hipEventRecord(e.lane_events[stp.op], stream_of(o.lane)));
-    }
-    // join the side lanes that took part back into lane 0 (required to end the capture). A lane without ops under this plan
-    // (the mask-coefficient lanes of a detect graph) never forked: touching it here would tie a non-captured event into the
-    // capture, so it is left alone.
-    for (int l : e.lanes_used) {
-        HIPCHK(hipEventRecord(e.lane_events[n + l], e.lane_streams[l]));
-        HIPCHK(hipStreamWaitEvent(e.own_stream, e.lane_events[n + l], 0));
-    }
-    return YP_OK;
+        hipStreamCaptureStatus stt = hipStreamCaptureStatusNone;
+        unsigned long long id = 0;
+        hipGraph_t g = nullptr;
+        const hipGraphNode_t* dn = nullptr;
+        size_t nd = 0;
+        HIPCHK(hipStreamGetCaptureInfo_v2(cs, &stt, &id, &g, &dn, &nd));
+        if (stt != hipStreamCaptureStatusActive) return fail(YP_ERR_HIP, "capture invalidated at op '%s'", o.name.c_str());
+        tail.assign(dn, dn + nd);
+        return YP_OK;
+    };
+    // the capture ends behind every lane's tail (nothing to join: there is only this stream)
+    auto finish = [&](std::vector<hipGraphNode_t>& all) -> int {
+        HIPCHK(hipStreamUpdateCaptureDependencies(cs, all.empty() ? nullptr : all.data(), all.size(), hipStreamSetCaptureDependencies));
+        return YP_OK;
+    };
+    return walk_lane_dag<hipGraphNode_t>(e, launch, finish, &e.g_edges_expected);
 }
 
 static int run_all(yp_engine& e, const RunArgs& a, hipStream_t st) {
@@ -1803,11 +1849,8 @@ int yp_destroy(yp_engine* e) {
     if (e->o_det) { (void)hipFree(e->o_det); (void)hipFree(e->o_idx); (void)hipFree(e->o_coeff); }
     drop_graph(*e);
     if (e->ev_in) (void)hipEventDestroy(e->ev_in);
-    if (e->ev_out) (void)hipEventDestroy(e->ev_out);
     if (e->ev_done) (void)hipEventDestroy(e->ev_done);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
-    for (auto ls : e->lane_streams) (void)hipStreamDestroy(ls);
-    for (auto ev : e->lane_events) (void)hipEventDestroy(ev);
     delete e;
     return YP_OK;
 }
@@ -1866,7 +1909,7 @@ int yp_finalize(yp_engine* e) {
     }
     HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
     e->finalized = true;
     return YP_OK;
 }
@@ -2016,8 +2059,6 @@ static int prepare(yp_engine* e, int B, int H, int W, const uint8_t* in, float* 
         }
         rc = build_lane_schedule(*e);
         if (rc != YP_OK) return rc;
-        rc = ensure_lane_resources(*e);
-        if (rc != YP_OK) return rc;
         e->warmed = false;
     }
     if (!e->warmed) {
@@ -2043,16 +2084,38 @@ static int push_nms_params(yp_engine* e, hipStream_t st) {
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-static int forward_eager(yp_engine* e, const RunArgs& a, hipStream_t st) {
-    int rc = push_nms_params(e, st);
-    return rc != YP_OK ? rc : run_all(*e, a, st);
+// Stream contract of yp_forward. Forwards of ONE engine share its arena, workspaces and device-side parameter blocks, so they must execute
+// one after the other. Calls on the same stream are ordered by the stream. A call on a DIFFERENT stream than the previous one first makes
+// its stream wait for ev_done - the event every forward (eager or replay) records behind its last launch - so a warm-up on one stream
+// followed by steps on another, or predict() under changing torch streams, cannot overlap two forwards of one engine. Cost: one
+// hipEventRecord per forward, one hipStreamWaitEvent per stream change.
+static int order_after_previous(yp_engine* e, hipStream_t st) {
+    if (e->have_last && e->last_stream != st) HIPCHK(hipStreamWaitEvent(st, e->ev_done, 0));
+    return YP_OK;
+}
+static int mark_done(yp_engine* e, hipStream_t ran_on, hipStream_t caller) {
+    HIPCHK(hipEventRecord(e->ev_done, ran_on));
+    e->last_stream = caller; e->have_last = true;
+    return YP_OK;
 }
 
-// hipGraph replay ON THE CALLER'S STREAM when that is not the legacy null stream (round 3; before: on the engine's own stream behind an event pair - the caller's stream then waited
-// for the replay and the next replay waited for the caller's stream, a ping-pong that left the GPU idle for ~20 us between steps, and a copy
-// kernel moved the results). The graph is captured on the engine's own stream (capture needs a stream nothing else uses) but an executable
-// graph launches on any stream; its lanes are internal fork / join edges. It is specialised on the plan, the INPUT pointer and - in direct
-// mode - the output pointers.
+static int forward_eager(yp_engine* e, const RunArgs& a, hipStream_t st) {
+    int rc = order_after_previous(e, st);
+    if (rc == YP_OK) rc = push_nms_params(e, st);
+    if (rc == YP_OK) rc = run_all(*e, a, st);
+    return rc != YP_OK ? rc : mark_done(e, st, st);
+}
+
+// hipGraph replay ON THE CALLER'S STREAM when that is not the legacy null stream (a replay on a stream of the engine's own, behind an event pair,
+// left the GPU idle for ~20 us between steps and needed a copy kernel for the results). The graph is captured on the engine's own stream
+// (capture needs a stream nothing else uses; capture_dag) but an executable graph launches on any stream. It is specialised on the plan,
+// the INPUT pointer and - in direct mode - the output pointers.
+// Lifetime rule: an executable is destroyed only (i) here, after hipEventSynchronize(ev_done) - ev_done was recorded behind the last launch
+// on the very stream that launch ran on, whichever stream that was -, (ii) in allocate_plan / yp_tuning_import / yp_destroy after a device
+// synchronisation, (iii) in yp_set_graph after the same hipEventSynchronize.
+// The legacy NULL stream: hipGraphLaunch of a multi-branch graph on stream 0 faulted inside the runtime (ROCm 7.2, deterministic in
+// tests/test_gpu_fullsize.py with the event-built graphs of round 3). A caller on stream 0 gets the engine's own stream in between: its
+// stream-0 work -> ev_in -> replay on own_stream -> ev_done -> stream 0.
 static int forward_replay(yp_engine* e, const uint8_t* in_dev, int B, int H, int W, float* det_out, int32_t* idx_out, float* coeff_out, hipStream_t st) {
     int rc;
     const bool seg = e->desc.task == YP_TASK_SEGMENT;
@@ -2061,28 +2124,35 @@ static int forward_replay(yp_engine* e, const uint8_t* in_dev, int B, int H, int
     if (e->direct_out && same_plan && (e->gkey.det != det_out || e->gkey.idx != idx_out || e->gkey.coeff != cf) && ++e->out_changes >= 2)
         e->direct_out = false;                        // this caller rotates its output buffers: engine-owned results + copy-out from now on
     static const int own_mode = [] { const char* v = std::getenv("YOLOP_REPLAY_OWN_STREAM"); return v ? atoi(v) : 0; }();   // A/B switch: 1 = round 2's path, 2 = own stream + direct outputs
-    // The legacy NULL stream is the exception: hipGraphLaunch of a re-captured multi-lane graph on stream 0 faulted inside the runtime
-    // (ROCm 7.2; deterministic in tests/test_gpu_fullsize.py, not under a non-default stream, not with the engine's own stream). A caller
-    // on the null stream therefore gets the engine's own stream + the event pair; bench.py runs its steps under a side stream.
     const bool own = own_mode != 0 || st == nullptr;
     const bool direct = own_mode != 1 && e->direct_out && det_out && idx_out && (!seg || cf);
     RunArgs ag = direct ? RunArgs{in_dev, det_out, idx_out, cf} : RunArgs{in_dev, e->o_det, e->o_idx, seg ? e->o_coeff : nullptr};
     if (!same_plan || e->gkey.det != ag.det || e->gkey.idx != ag.idx || e->gkey.coeff != ag.coeff) {
         if (e->gexec) {
             // the previous executable may still be running (replays are asynchronous): never destroy it under the GPU
-            if (e->ev_done) HIPCHK(hipEventSynchronize(e->ev_done));
+            if (e->have_last) HIPCHK(hipEventSynchronize(e->ev_done));
             drop_graph(*e);
         }
         hipGraph_t g = nullptr;
         HIPCHK(hipStreamBeginCapture(e->own_stream, hipStreamCaptureModeThreadLocal));
-        rc = e->use_lanes ? run_all_lanes(*e, ag) : run_all(*e, ag, e->own_stream);
+        rc = e->use_lanes ? capture_dag(*e, ag) : run_all(*e, ag, e->own_stream);
         hipError_t ce = hipStreamEndCapture(e->own_stream, &g);
         if (rc != YP_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
         if (ce != hipSuccess) return fail(YP_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(ce));
         e->gsrc = g;
+        {
+            size_t nn = 0, ne = 0;
+            HIPCHK(hipGraphGetNodes(g, nullptr, &nn));
+            HIPCHK(hipGraphGetEdges(g, nullptr, nullptr, &ne));
+            e->g_nodes = (int)nn; e->g_edges = (int)ne;
+            if (!e->use_lanes) e->g_edges_expected = (int)nn - 1;
+        }
         HIPCHK(hipGraphInstantiate(&e->gexec, g, nullptr, nullptr, 0));
+        ++e->n_captures;
         e->gkey.B = B; e->gkey.H = H; e->gkey.W = W; e->gkey.in = in_dev; e->gkey.det = ag.det; e->gkey.idx = ag.idx; e->gkey.coeff = ag.coeff;
     }
+    rc = order_after_previous(e, st);
+    if (rc != YP_OK) return rc;
     hipStream_t rs = st;
     if (own) {
         rs = e->own_stream;
@@ -2096,8 +2166,8 @@ static int forward_replay(yp_engine* e, const uint8_t* in_dev, int B, int H, int
         const size_t rows = (size_t)B * e->desc.max_det;
         HIPCHK(launch_copy_out(e->o_det, det_out, e->o_idx, idx_out, e->o_coeff, cf, rows, rs));
     }
-    if (!e->ev_done) HIPCHK(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
-    HIPCHK(hipEventRecord(e->ev_done, rs));
+    rc = mark_done(e, rs, st);
+    if (rc != YP_OK) return rc;
     if (own) HIPCHK(hipStreamWaitEvent(st, e->ev_done, 0));
     return YP_OK;
 }
@@ -2187,6 +2257,42 @@ int yp_debug_head_winners(yp_engine* e, int32_t* sel_host, float* box_host, floa
     return (h->sparse_box ? 1 : 0) | (h->sparse_cf ? 2 : 0);
 }
 
+int yp_debug_graph_info(const yp_engine* e, int64_t* out6) {
+    if (!e || !out6) return fail(YP_ERR_ARG, "yp_debug_graph_info: null argument");
+    out6[0] = e->n_captures; out6[1] = e->g_nodes; out6[2] = e->g_edges; out6[3] = e->g_edges_expected;
+    out6[4] = (int64_t)e->lanes_used.size() + 1; out6[5] = e->gexec ? 1 : 0;
+    return YP_OK;
+}
+
+int yp_debug_head_positions(yp_engine* e, int64_t* out6) {
+    if (!e || !out6) return fail(YP_ERR_ARG, "yp_debug_head_positions: null argument");
+    for (int i = 0; i < 6; ++i) out6[i] = 0;
+    if (!e->allocated) return fail(YP_ERR_STATE, "no forward has run yet");
+    const Op* h = nullptr;
+    for (const Op& o : e->ops) if (o.kind == OP_HEAD) h = &o;
+    if (!h || !(h->sparse_box || h->sparse_cf) || !e->sp_ws) return 0;
+    HIPCHK(hipSetDevice(e->device));
+    HIPCHK(hipDeviceSynchronize());
+    const SparseWs ws = sparse_ws_layout(*e);
+    const char* base = (const char*)e->sp_ws;
+    int pc[8];
+    HIPCHK(hipMemcpy(pc, base + ws.pcount, sizeof(pc), hipMemcpyDeviceToHost));     // [4..7): the counts stage 2 saved before emptying the lists
+    std::vector<int> wc((size_t)e->pB * 3);
+    HIPCHK(hipMemcpy(wc.data(), base + ws.wcount, wc.size() * 4, hipMemcpyDeviceToHost));
+    for (int l = 0; l < 3; ++l) {
+        out6[l] = std::min(pc[4 + l], ws.plist_cap[l]);
+        for (int b = 0; b < e->pB; ++b) out6[3 + l] += wc[(size_t)b * 3 + l];
+    }
+    return 1;
+}
+
+__global__ void op_marker_kernel(int* sink) { if (sink) *sink = 0; }
+int yp_debug_marker(void* stream) {
+    hipLaunchKernelGGL(op_marker_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (int*)nullptr);
+    HIPCHK(hipGetLastError());
+    return YP_OK;
+}
+
 int yp_debug_contour_clocks(uint64_t* out12) {
     if (!out12) return fail(YP_ERR_ARG, "yp_debug_contour_clocks: null output");
     HIPCHK(hipDeviceSynchronize());
@@ -2254,6 +2360,27 @@ int yp_debug_host_selftest(yp_engine* e) {
     int used = 0;
     for (int l = 1; l < e->n_lanes; ++l) used += seen[l];
     if (used != (int)e->lanes_used.size()) return fail(YP_ERR_STATE, "internal: %d side lanes launch but %zu are joined", used, e->lanes_used.size());
+    // the graph capture_dag builds from this schedule, walked with integer node ids: every dependency is an EARLIER node (so the graph is
+    // acyclic and no handle of another capture can appear), an op without dependencies exists only before lane 0 has launched anything
+    // (it reads the caller's frames alone), and the capture ends behind the tail of every lane that launched
+    {
+        int next_id = 0, lane0_nodes = 0, bad = 0, nsteps = 0;
+        auto launch = [&](const yp_engine::LaneStep& stp, std::vector<int>& deps, std::vector<int>& tail) -> int {
+            for (int d : deps) if (d < 0 || d >= next_id) ++bad;
+            if (deps.empty() && lane0_nodes > 0) ++bad;
+            if (e->ops[stp.op].lane == 0) ++lane0_nodes;
+            tail.assign(1, next_id++);
+            ++nsteps;
+            return YP_OK;
+        };
+        size_t joined = 0;
+        auto finish = [&](std::vector<int>& all) -> int { joined = all.size(); return YP_OK; };
+        int edges = 0;
+        rc = walk_lane_dag<int>(*e, launch, finish, &edges);
+        if (rc != YP_OK) return rc;
+        if (bad) return fail(YP_ERR_STATE, "internal: the capture DAG has %d dangling or forward dependencies", bad);
+        if (joined != e->lanes_used.size() + 1 || nsteps != (int)e->lane_steps.size()) return fail(YP_ERR_STATE, "internal: the capture ends behind %zu lane tails, %zu lanes launched", joined, e->lanes_used.size() + 1);
+    }
     return (int)e->lane_steps.size() + (acc == 0 ? 0 : 0);
 }
 
@@ -2312,7 +2439,7 @@ int yp_set_graph(yp_engine* e, int enable) {
         // only a change of the LANE mode invalidates the captured executable; switching between eager launches and replay keeps it, so a
         // caller that alternates one-frame calls (eager) with batches (replay) pays neither a sync nor a re-capture
         HIPCHK(hipSetDevice(e->device));
-        if (e->ev_done) HIPCHK(hipEventSynchronize(e->ev_done));
+        if (e->have_last) HIPCHK(hipEventSynchronize(e->ev_done));
         drop_graph(*e);
         e->auto_replay.clear();
     }

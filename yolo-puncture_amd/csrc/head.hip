@@ -577,7 +577,7 @@ __global__ __launch_bounds__(HT) void head_select_kernel(const HeadParams p, con
     }
     if constexpr (MODE == 2) {
         // the position lists of this forward have been consumed (the branch kernels ran between the two stages): empty them for the next one
-        if (b == 0 && tid < 3 && p.sp_pcount) p.sp_pcount[tid] = 0;
+        if (b == 0 && tid < 3 && p.sp_pcount) { p.sp_pcount[4 + tid] = p.sp_pcount[tid]; p.sp_pcount[tid] = 0; }   // ([4..7): what yp_debug_head_positions reports)
     }
     HEAD_STAMP(6);
 }

@@ -242,7 +242,7 @@ bool head_branch_valid(const HeadBranchParams& p) {
         if ((p.Cin[l] % 32) != 0 || p.Cin[l] < 32 || (p.x_stride[l] & 7) || (p.x_coff[l] & 7) || p.x_bytes[l] >= (1ull << 31)) return false;
         if (p.Kpad0[l] != 9 * p.Cin[l] || p.Kpad1[l] != 9 * p.cmid || p.Kpad2[l] != (p.cmid + 31) / 32 * 32) return false;   // no padded taps
     }
-    if (p.plist && (p.t0_bytes >= (1ull << 31) || p.B >= 2048 || p.H[0] * p.W[0] >= (1 << 20))) return false;   // 32-bit gather offsets, image << 20 | pixel
+    if (p.t0_bytes >= (1ull << 31) || p.B >= 2048 || p.H[0] * p.W[0] >= (1 << 20)) return false;   // 32-bit gather offsets, image << 20 | pixel (sizes are plan-time facts: checked before the workspace exists)
     return p.maxk >= p.max_det && p.max_det <= 512;
 }
 

@@ -72,6 +72,12 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_set_nms.restype = C.c_int
     lib.yp_debug_host_selftest.argtypes = [vp]
     lib.yp_debug_host_selftest.restype = C.c_int
+    lib.yp_debug_graph_info.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.yp_debug_graph_info.restype = C.c_int
+    lib.yp_debug_head_positions.argtypes = [vp, C.POINTER(C.c_int64)]
+    lib.yp_debug_head_positions.restype = C.c_int
+    lib.yp_debug_marker.argtypes = [vp]
+    lib.yp_debug_marker.restype = C.c_int
     lib.yp_debug_force_conv_cfg.argtypes = [C.c_int]
     lib.yp_debug_ablation.argtypes = [C.c_int]
     lib.yp_debug_head_clocks.argtypes = [C.POINTER(C.c_uint64)]
@@ -98,7 +104,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output", "yp_op_input",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_tuning_export", "yp_tuning_import", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_head_branch_clocks", "yp_debug_head_winners", "yp_debug_contour_clocks", "yp_debug_host_selftest", "yp_letterbox", "yp_mask_contours",
+           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_tuning_export", "yp_tuning_import", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_head_branch_clocks", "yp_debug_head_winners", "yp_debug_contour_clocks", "yp_debug_host_selftest", "yp_debug_graph_info", "yp_debug_head_positions", "yp_debug_marker", "yp_letterbox", "yp_mask_contours",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy",
            "yp_u2net_create", "yp_u2net_destroy", "yp_u2net_weight_count", "yp_u2net_weight_info", "yp_u2net_set_weight", "yp_u2net_finalize",
            "yp_u2net_forward", "yp_u2net_set_graph", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
@@ -405,6 +411,19 @@ class Engine:
         cf = torch.zeros((B, self.max_det, 32), dtype=torch.float32)
         mode = self._chk(self.lib.yp_debug_head_winners(self._h, C.c_void_p(sel.data_ptr()), C.c_void_p(box.data_ptr()), C.c_void_p(cf.data_ptr())))
         return mode, sel, box, cf
+
+    def graph_info(self) -> dict:
+        """What the last hipGraph capture built (yp_debug_graph_info): captures so far, nodes, edges, the lane schedule's edge count."""
+        v = (C.c_int64 * 6)()
+        self._chk(self.lib.yp_debug_graph_info(self._h, v))
+        return dict(captures=int(v[0]), nodes=int(v[1]), edges=int(v[2]), schedule_edges=int(v[3]), lanes=int(v[4]), live=bool(v[5]))
+
+    def head_positions(self) -> Optional[dict]:
+        """Winners-only head, last forward: distinct 3x3-neighbourhood positions and winners per level (P3, P4, P5); None = dense head."""
+        v = (C.c_int64 * 6)()
+        if self._chk(self.lib.yp_debug_head_positions(self._h, v)) == 0:
+            return None
+        return dict(positions=[int(v[i]) for i in range(3)], winners=[int(v[3 + i]) for i in range(3)])
 
     def profile(self, im: torch.Tensor, iters: int = 5) -> List[dict]:
         """Per-op HIP-event timing (eager, one event pair per launch) on the current stream."""

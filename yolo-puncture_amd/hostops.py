@@ -217,15 +217,56 @@ def external_contours(mask: np.ndarray) -> List[np.ndarray]:
     return [p for _, p in found]
 
 
+POLYGON_STRATEGIES = ("all", "largest", "all_merged")
+
+
+def merge_contours(contours: List[np.ndarray]) -> np.ndarray:
+    """"all" of the LATER 8.3.x releases [U]: `masks2segments` there joins several contours with `merge_multi_segment` (the COCO converter's
+    routine) instead of laying them end to end - consecutive contours of the list are bridged at their closest pair of points (first
+    minimum in row-major order of the squared-distance table), the first and the last contour are walked whole and closed, a middle one
+    from its entry point to its exit point on the way out and the rest of it on the way back. Same point set as the concatenation (hence
+    the same hull and minimum-area rectangle), another vertex order."""
+    segs = [np.asarray(c).reshape(-1, 2) for c in contours]
+    n = len(segs)
+    if n == 0:
+        return np.zeros((0, 2), dtype=np.int32)
+    if n == 1:
+        return segs[0]
+    near = [[] for _ in range(n)]
+    for i in range(1, n):
+        a, b = segs[i - 1].astype(np.int64), segs[i].astype(np.int64)
+        d = ((a[:, None, :] - b[None, :, :]) ** 2).sum(-1)
+        j = int(d.argmin())
+        near[i - 1].append(j // d.shape[1])
+        near[i].append(j % d.shape[1])
+    out, back = [], []
+    for i in range(n):
+        idx = near[i]
+        seg = segs[i]
+        if len(idx) == 2 and idx[0] > idx[1]:
+            idx, seg = idx[::-1], seg[::-1]
+        seg = np.roll(seg, -idx[0], axis=0)
+        seg = np.concatenate([seg, seg[:1]])
+        if i == 0 or i == n - 1:
+            out.append(seg)
+        else:
+            out.append(seg[:idx[1] - idx[0] + 1])
+            back.append(seg[abs(near[i][1] - near[i][0]):])
+    return np.concatenate(out + back[::-1], axis=0)
+
+
 def mask_polygon(mask: np.ndarray, strategy: str = "all") -> np.ndarray:
-    """ultralytics `masks2segments(mask, strategy)` for one mask [U]: int32 [m,2] (x,y); [0,2] for an empty mask."""
-    if strategy not in ("all", "largest"):
-        raise ValueError(f"strategy must be 'all' or 'largest', got {strategy!r}")
+    """ultralytics `masks2segments(mask, strategy)` for one mask [U]: int32 [m,2] (x,y); [0,2] for an empty mask. "all" = every external
+    contour laid end to end, "all_merged" = the same contours bridged at their closest points (later 8.3.x, merge_contours)."""
+    if strategy not in POLYGON_STRATEGIES:
+        raise ValueError(f"strategy must be one of {POLYGON_STRATEGIES}, got {strategy!r}")
     c = external_contours(mask)
     if not c:
         return np.zeros((0, 2), dtype=np.int32)
     if strategy == "all":
         return np.concatenate(c, axis=0)
+    if strategy == "all_merged":
+        return merge_contours(c).astype(np.int32)
     return c[int(np.argmax([len(x) for x in c]))]
 
 

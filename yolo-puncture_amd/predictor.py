@@ -102,7 +102,10 @@ class Boxes:
 
 
 MASK_POLYGON_STRATEGY = "all"     # ultralytics masks2segments(strategy=...) [U]: "all" is the default of the 8.3.x line the app's YOLO11 weights
-                                  # need (every external contour, concatenated); "largest" that of 8.0-8.2. SURVEY A.7; set before predicting.
+                                  # need - every external contour, laid end to end (8.1 ... early 8.3) or, "all_merged", bridged at their closest
+                                  # points with merge_multi_segment (later 8.3.x); "largest" is the default of 8.0. All three give the same
+                                  # minimum-area rectangle whenever a mask has one contour, and "all" / "all_merged" always (same point set).
+                                  # SURVEY A.7; set before predicting.
 
 
 class Masks:
@@ -170,13 +173,21 @@ class Masks:
         mh, mw = self.shape[1:]
         poly, rect = None, None
         u8 = self._u8
+        one = None
         if u8 is None and isinstance(self._data, torch.Tensor) and self._data.is_cuda:
-            u8 = (self._data[i:i + 1] > 0.5).to(torch.uint8)
-            polys, rects = mask_contours_device(u8, strategy=self.strategy)
-            poly, rect = polys[0], rects[0]
+            one = (self._data[i:i + 1] > 0.5).to(torch.uint8)
         elif u8 is not None and u8.is_cuda:
-            polys, rects = mask_contours_device(u8[i:i + 1], strategy=self.strategy)
-            poly, rect = polys[0], rects[0]
+            one = u8[i:i + 1]
+        if one is not None:
+            if self.strategy == "all_merged":             # the device lists every external contour ("all") with its length; bridged on the host
+                polys, rects, parts = mask_contours_device(one, strategy="all", want_parts=True)
+                poly, rect = polys[0], rects[0]
+                if poly is not None and len(parts[0]) > 1:
+                    cuts = np.cumsum(parts[0])[:-1]
+                    poly = hostops.merge_contours(np.split(poly, cuts)).astype(np.int32)
+            else:
+                polys, rects = mask_contours_device(one, strategy=self.strategy)
+                poly, rect = polys[0], rects[0]
         if poly is None:                                  # (no GPU copy, or the device pass declined this mask: host trace)
             d = self.data[i]
             host = d.detach().cpu().numpy() if isinstance(d, torch.Tensor) else np.asarray(d)
