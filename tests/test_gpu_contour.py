@@ -44,16 +44,45 @@ def _brute_min_rect(points):
             return float(np.hypot(*(q[-1] - q[0]))), 0.0
         return 0.0, 0.0
     hv = p[ConvexHull(p).vertices]
-    best = None
+    cand = []
     for i in range(len(hv)):
         e = hv[(i + 1) % len(hv)] - hv[i]
         t = np.arctan2(e[1], e[0])
         R = np.array([[np.cos(t), np.sin(t)], [-np.sin(t), np.cos(t)]])
         q = p @ R.T
         w, h = q[:, 0].max() - q[:, 0].min(), q[:, 1].max() - q[:, 1].min()
-        if best is None or w * h < best[0]:
-            best = (w * h, max(w, h), min(w, h))
+        cand.append((w * h, max(w, h), min(w, h)))
+    best = min(cand)
     return best[1], best[2]
+
+
+def _assert_rect(rect_row, points, where=None):
+    """The device rectangle of `points` against the brute-force form. Several hull edges can give rectangles of the SAME minimal area with
+    different sides (a 3-pixel right triangle: 2 x 1 and sqrt2 x sqrt2); which one cv2.minAreaRect reports is decided by float32 rounding
+    inside its calipers loop and cannot be pinned without cv2 - the area is asserted always, the sides when the minimum is unique."""
+    from scipy.spatial import ConvexHull
+    p = np.unique(np.asarray(points, dtype=np.float64).reshape(-1, 2), axis=0)
+    L, S = float(rect_row[0]), float(rect_row[1])
+    bl, bw = _brute_min_rect(points)
+    assert L * S == pytest.approx(bl * bw, rel=1e-9, abs=1e-7), (where, L, S, bl, bw)
+    if len(p) < 3 or np.linalg.matrix_rank(p - p[0]) < 2:
+        assert L == pytest.approx(bl, rel=1e-9, abs=1e-9) and S == pytest.approx(bw, abs=1e-7), (where, L, S, bl, bw)
+        return
+    hv = p[ConvexHull(p).vertices]
+    areas = []
+    for i in range(len(hv)):
+        e = hv[(i + 1) % len(hv)] - hv[i]
+        t = np.arctan2(e[1], e[0])
+        R = np.array([[np.cos(t), np.sin(t)], [-np.sin(t), np.cos(t)]])
+        q = p @ R.T
+        w, h = q[:, 0].max() - q[:, 0].min(), q[:, 1].max() - q[:, 1].min()
+        areas.append((w * h, max(w, h), min(w, h)))
+    amin = min(a for a, _, _ in areas)
+    shapes = {(round(l, 6), round(s_, 6)) for a, l, s_ in areas if a <= amin * (1 + 1e-9) + 1e-9}
+    if len(shapes) == 1:
+        assert L == pytest.approx(bl, rel=1e-9, abs=1e-9) and S == pytest.approx(bw, rel=1e-9, abs=1e-7), (where, L, S, bl, bw)
+    else:
+        assert any(L == pytest.approx(l, abs=1e-5) and S == pytest.approx(s_, abs=1e-5) for l, s_ in shapes), (where, L, S, shapes)
 
 
 def _cases():
@@ -152,8 +181,7 @@ def test_contour_and_rect_match_host(name, mask, strategy):
     assert np.array_equal(got, want)                                       # integer work: identical, point for point, same order
     assert parts[0] == want_parts                                          # the list's contours, bottom-up
     if want.shape[0] >= 3:                                                 # rectangle: qhull + rotation of all points (no product code)
-        bl, bw = _brute_min_rect(want)
-        assert rect[0, 0] == pytest.approx(bl, rel=1e-9, abs=1e-9) and rect[0, 1] == pytest.approx(bw, rel=1e-9, abs=1e-7)
+        _assert_rect(rect[0], want, name)
     elif want.shape[0] == 2:
         assert rect[0, 0] == pytest.approx(float(np.hypot(*(want[1] - want[0]).astype(np.float64))), abs=1e-12) and rect[0, 1] == pytest.approx(0.0, abs=1e-12)
     else:
@@ -190,8 +218,7 @@ def test_random_masks_against_suzuki_abe():
                 continue
             assert np.array_equal(polys[i], want), (i, strategy)
             if want.shape[0] >= 3:
-                bl, bw = _brute_min_rect(want)
-                assert rect[i, 0] == pytest.approx(bl, rel=1e-9, abs=1e-9) and rect[i, 1] == pytest.approx(bw, rel=1e-9, abs=1e-7), (i, strategy)
+                _assert_rect(rect[i], want, (i, strategy))
         assert declined < N // 10
 
 

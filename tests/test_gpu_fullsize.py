@@ -58,9 +58,11 @@ def _check_head_against_oracle(eng, orc, out, B, H, W, nc, min_gap_frac=0.6):
     det, idx = out["det"].cpu(), out["idx"].cpu().long()
     k = want.shape[1]
     assert float((det[:, :k, 4] - want[..., 4]).abs().max()) < 1e-6                  # same sigmoid of the same fp32 logit
+    assert float(((det[:, :k, 4] - want[..., 4]).abs() / want[..., 4].clamp_min(1e-30)).max()) < 4e-6   # ... also where the scores are small (a few ulp)
     gap_ok = torch.ones_like(want[..., 4], dtype=torch.bool)
-    gap_ok[:, :-1] &= (want[:, :-1, 4] - want[:, 1:, 4]) > 1e-6                       # rows that are not float near-ties
-    gap_ok[:, 1:] &= (want[:, :-1, 4] - want[:, 1:, 4]) > 1e-6
+    tol = torch.minimum(torch.full_like(want[:, :-1, 4], 1e-6), 8.0 * 2.0 ** -23 * want[:, :-1, 4])   # 1e-6, or 8 ulp of a small score
+    gap_ok[:, :-1] &= (want[:, :-1, 4] - want[:, 1:, 4]) > tol                        # rows that are not float near-ties
+    gap_ok[:, 1:] &= (want[:, :-1, 4] - want[:, 1:, 4]) > tol
     print(f"rows with a clear score gap: {float(gap_ok.float().mean()):.3f}")
     assert gap_ok.float().mean() > min_gap_frac                                       # the data must pose an ordering problem
     assert torch.equal(idx[:, :k][gap_ok], widx[gap_ok])                              # integer work: bit-exact

@@ -1595,17 +1595,20 @@ static int build_lane_schedule(yp_engine& e) {
 //
 // Rounds 1-3 captured the lanes as streams: a cross-lane dependency was hipEventRecord on the producer's stream + hipStreamWaitEvent on the
 // consumer's, with one set of events kept for the engine's life and re-used by every capture. A replay of a RE-captured graph of that
-// kind died with a host SIGSEGV inside hipGraphLaunch (tests/test_gpu_fullsize.py: always with the caller on the legacy NULL stream, one
-// run in three otherwise). What those records have in common is the second capture: an event that was recorded inside capture #1 still
-// carries capture #1's state (the graph nodes "in front of" the record) when capture #2 begins, and whenever a record inside capture #2
-// finds nothing new to attach (a fork recorded before the first node of its stream, a lane that launched nothing) the wait that follows
-// takes the STALE node pointers of the destroyed graph #1 as dependencies. Nothing in HIP's interface lets a caller clear an event's
-// capture state, so the rule here is structural:
+// kind died with a host SIGSEGV inside hipGraphLaunch (round 3, tests/test_gpu_fullsize.py: always with the caller on the legacy NULL
+// stream, one run in three otherwise; Python-level stack only, no native backtrace was ever obtained). What the crashing runs share and
+// no passing configuration had is cross-stream capture state that outlives a capture: events recorded inside capture #1 (and side
+// streams that were pulled into it) entering capture #2. The hypothesis - an event whose record finds nothing new to attach keeps the
+// node handles of the destroyed graph #1 - was put to a stand-alone probe (tools/micro/recapture_probe.hip: 6 lanes, 20 re-captures per
+// mode with re-used events, fresh events, an early fork, NULL-stream replays): every mode passes on ROCm 7.2, so the fault is NOT
+// reproduced in isolation and its cause inside the runtime remains unestablished. What can be done is to take the whole mechanism away:
 //   RULE: no event and no second stream ever takes part in a capture. The op list is captured on own_stream alone; before each op the
 //   stream's dependency set is REPLACED (hipStreamUpdateCaptureDependencies, hipStreamSetCaptureDependencies) by the graph nodes the lane
 //   schedule names - the tail of the op's own lane and the tails of the ops it waits for - and after the op the new tail is read back
-//   (hipStreamGetCaptureInfo_v2). Node handles belong to the graph under construction and die with it; nothing outlives a capture.
-// The resulting graph has the same edges the stream form produced (yp_debug_graph_info reports nodes / edges against the schedule's count).
+//   (hipStreamGetCaptureInfo_v2). Node handles belong to the graph under construction and die with it; nothing outlives a capture,
+//   so capture #2 cannot see anything of capture #1.
+// The resulting graph has the same edges the stream form produced (yp_debug_graph_info reports nodes / edges against the schedule's count;
+// tests/test_gpu_ring.py holds replays of re-captured graphs, on alternating streams and on the NULL stream, to the eager results).
 // The walk both capture_dag and the host selftest use: `launch(step, deps, tail)` gets the dependency set of the step (sorted, unique) and
 // returns the tail its launches leave behind; `finish(all_tails)` gets the union of the lanes' tails.
 template <class Node, class Launch, class Finish>

@@ -84,7 +84,6 @@ class EngineRing:
         self._k = 0
         n = len(self.engines)
         self._stage = [None] * n         # the tensor engine j's graph reads (the caller's, or _own[j])
-        self._last_src = [None] * n      # (pointer, shape) of the frames engine j was last given
         self._own = [None] * n           # ring-owned staging tensors, made on first need
         self._outs = [None] * n          # ring-owned outputs for submit(out=None)
 
@@ -105,7 +104,11 @@ class EngineRing:
             e.tuning_import(B, H, W, cfgs)
             e.forward(frames)
         torch.cuda.synchronize(frames.device)
-        self.streams = [torch.cuda.Stream(frames.device) for _ in self.engines]
+        # The runtime maps streams onto a few hardware queues and two graphs on ONE queue cannot overlap (tools/ring_queue_probe.py, same
+        # box, same engines: default-priority streams 0 and 1 of torch's pool 1.864 ms per step = no overlap at all, streams 0 and 2
+        # 1.522 ms; which pairs collide depends on what else the process has created). Queues of different PRIORITY come from different
+        # pools, so neighbouring engines of the ring get streams of alternating priority: 1.524 ms whatever the pool's state.
+        self.streams = [torch.cuda.Stream(frames.device, priority=-(j & 1)) for j in range(len(self.engines))]
         for e, s in zip(self.engines, self.streams):
             # with more than one batch in flight every batch's graph is ONE chain on one stream (yp_set_graph mode 2): the other batch
             # fills the CUs that a lone graph fills with its concurrent head lanes, and a batch then occupies exactly one of the runtime's
@@ -116,14 +119,15 @@ class EngineRing:
                 e.forward(frames)
         torch.cuda.synchronize(frames.device)
 
-    def submit(self, frames: torch.Tensor, out=None):
+    def submit(self, frames: torch.Tensor, out=None, resident: bool = False):
         """A captured graph is specialised on its input and output POINTERS (yp_forward re-captures when they change, which blocks the
         host on the engine's previous batch). So every engine of the ring reads from a staging tensor of its own: the frames are copied
-        into it on the ring's stream (39 MB at 32 x 640 x 640: ~15 us) - unless the caller hands this engine the very tensor it was
-        handed last time (resident buffers, one per engine), which is then read in place. Either way an engine re-captures at most twice
-        after prepare(), whatever the caller brings. Results go to `out` when given (keep one `out` per engine from call to call and the
-        graph writes it directly; changing ones switch the engine to engine-owned results + a 0.3 MB copy-out) or, with out=None, to a
-        per-engine output set that is returned and overwritten by that engine's next batch."""
+        into it on the ring's stream (39 MB at 32 x 640 x 640: ~15 us). `resident=True` says that `frames` is a long-lived buffer the
+        caller will hand to this ring again (one buffer per engine, in the ring's round-robin order): it is read in place and the graph
+        is captured on it. Either way an engine re-captures only when the tensor it reads actually changes. Results go to `out` when
+        given (keep one `out` per engine from call to call and the graph writes it directly; changing ones switch the engine to
+        engine-owned results + a 0.3 MB copy-out) or, with out=None, to a per-engine output set that is returned and overwritten by that
+        engine's next batch."""
         if self.streams is None:
             self.prepare(frames)
         j = self._k % len(self.engines)
@@ -132,9 +136,6 @@ class EngineRing:
         s.wait_stream(torch.cuda.current_stream(frames.device))
         with torch.cuda.stream(s):
             src = frames.contiguous()
-            key = (src.data_ptr(), tuple(src.shape))
-            resident = self._last_src[j] == key            # the same tensor twice in a row on this engine: a resident buffer, read in place
-            self._last_src[j] = key
             if resident:
                 self._stage[j] = src
             else:
