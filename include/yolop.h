@@ -186,6 +186,10 @@ int yp_op_output(const yp_engine* e, int i, int* tensor, int* coff, int* C); /* 
 /* Input view of op i, and `c_read`: the channels a dense conv packed with padded taps actually reads per pixel (> C for 48- / 80-channel
    inputs: the surplus lanes meet zero weights; their bytes come from the next pixel or, at the very end, from the tensor's zeroed tail). */
 int yp_op_input(const yp_engine* e, int i, int* tensor, int* coff, int* C, int* c_read);
+/* Fused producer of op i under the current plan: *pre = index of the 1x1 conv that runs as the first stage of op i's kernel (pwsp_kernel:
+   1x1 -> depthwise conv / SPPF pool chain, one workgroup per image and channel slice), or -1; *pre_stored = 1 when that kernel also writes
+   the 1x1's own output tensor (it has other readers). The parity tests use it to teacher-force both results of such a launch. */
+int yp_op_fusion(const yp_engine* e, int i, int* pre, int* pre_stored);
 /* Debug stepping for per-op parity tests ("teacher forcing"): run ONE op of the current plan, and overwrite a
  * channel slice of an engine tensor from fp32 host data [B,H,W,C] (converted to the tensor's storage type). */
 int yp_run_op(yp_engine* e, int i, const uint8_t* in_dev, float* det_out, int32_t* idx_out, float* coeff_out, void* stream);
@@ -241,6 +245,9 @@ int yp_debug_head_winners(yp_engine* e, int32_t* sel_host, float* box_host, floa
 /* phase stamps of yp_mask_contours (mask 0): [0..6] 100-MHz ticks at box / bit image / candidates / trace / emit / hull / end, [8] candidates,
    [9] points of the winning contour, [10], [11] bounding box width, height */
 int yp_debug_contour_clocks(uint64_t* out12);
+/* phase stamps (core clock) of workgroup 0 in the last pwsp_kernel launch: [0] start, [1] prologue issued, [2] GEMM done, [3] epilogue done,
+   [4] behind the barrier, [5] spatial stage done, [8 + g] top of k-step g (g < 16) */
+int yp_debug_pwsp_clocks(uint64_t* out32);
 
 /* Host-only self-check of the executor for the current plan (parameter blocks, kernel symbols, tune-cache round trip, lane
  * schedule invariants). Needs no GPU; returns the number of scheduled launches or <0. Used by the CPU sanitizer build. */

@@ -134,16 +134,41 @@ def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc, want_tail=Fals
     out = eng.forward(imc)               # allocates the plan; results are recomputed op by op below
     torch.cuda.synchronize()
     ops = eng.plan(*shape)
-    if shape == (2, 256, 384):           # 8x12 P5 map: the 7x7 depthwise must run on the matrix-core kernel here
-        assert any(str(o.get("kernel", "")).startswith("dwconv_mfma") for o in ops), sorted({o.get("kernel") for o in ops})
+    if shape == (2, 256, 384):           # 8x12 P5 map: the 7x7 depthwise runs on the matrix-core kernel, or inside pwsp_kernel behind its 1x1 conv
+        k7 = [str(o.get("kernel", "")) for o in ops if o["name"].endswith("cv1.2")]
+        assert k7 and all(k.startswith(("dwconv_mfma", "pwsp_kernel") if fuse else "dwconv_mfma") for k in k7), k7
     rows = []
     from yolo_puncture_amd.weights import fold_state
     folded = fold_state(st)
-    nfused = ntail = 0
+    nfused = ntail = npwsp = 0
     for i, o in enumerate(ops):
         if o["kind"] == "head":
             continue
         eng.run_op(i, imc, out)
+        is_pwsp = str(o.get("kernel", "")).startswith("pwsp_kernel") and o.get("pre", -1) >= 0
+        if is_pwsp:
+            npwsp += 1
+        if is_pwsp and o["kind"] == "pool3":
+            # pwsp_kernel, SPPF form: 1x1 conv -> three chained 5x5 max-pools in one launch. The pools are exact operators applied to the
+            # kernel's own 1x1 result, which is within 1 bf16 ulp of the oracle's on a small fraction of elements - so are the pooled maps
+            pre = ops[o["pre"]]
+            y = [taps[pre["name"]]]
+            for _ in range(3):
+                y.append(torch.nn.functional.max_pool2d(y[-1], 5, 1, 2))
+            t, c0, cc = o["out"]
+            want = nchw_to_nhwc(torch.cat(y[1:], 1))
+            got = eng.read_tensor(t)[..., c0:c0 + cc]
+            u = _ulps_bf16(got, want)
+            assert float(u.max()) <= 1.0 + 1e-6 and float((u > 0).float().mean()) < 0.02, (o["name"], float(u.max()), float((u > 0).float().mean()))
+            rows.append((o["name"], o["kind"], float(u.max()), float((u > 0).float().mean())))
+            eng.write_tensor(t, c0, want)
+            tp, cp0, cpc = pre["out"]
+            if o["pre_stored"]:                                    # the 1x1's own output, written by the same launch: the strict contract again
+                gp = eng.read_tensor(tp)[..., cp0:cp0 + cpc]
+                up = _ulps_bf16(gp, nchw_to_nhwc(taps[pre["name"]]))
+                assert float(up.max()) <= 1.0 + 1e-6 and float((up > 0).float().mean()) < 0.02, (pre["name"], float(up.max()))
+            eng.write_tensor(tp, cp0, nchw_to_nhwc(taps[pre["name"]]))
+            continue
         if o["name"] not in taps:
             continue
         t, c0, cc = o["out"]
@@ -174,7 +199,7 @@ def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc, want_tail=Fals
             err = rel_err(got, want)
             rows.append((o["name"], o["kind"], err, 0.0))
             assert err < 2e-5, (o["name"], err)
-        elif str(o.get("kernel", "")).startswith(("conv_dwpw", "frontend_kernel", "c2f_fused_kernel", "scdown_fused_kernel")) or \
+        elif str(o.get("kernel", "")).startswith(("conv_dwpw", "frontend_kernel", "c2f_fused_kernel", "scdown_fused_kernel")) or is_pwsp or \
                 (str(o.get("kernel", "")).endswith(",false,false,true>") and "halo_s2" in str(o.get("kernel", ""))) or \
                 (o["kernel"] == "-" and o["kind"] == "conv" and i + 1 < len(ops) and ",tail," in str(ops[i + 1].get("kernel", ""))):
             # (last case: the pointwise conv of a dw -> pw -> logits TAIL kernel; stepped on its own, yp_run_op runs it as the two-stage fused pair)
@@ -183,7 +208,7 @@ def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc, want_tail=Fals
             # of every unfused op), and such a flip of element j moves output co by |w[co,j]| * ulp(t_j). Tolerance:
             # 1 output ulp + 4 simultaneous flips at the largest weight and the largest intermediate ulp; the differing
             # fraction stays small because almost all such moves are far below an output ulp.
-            dw_name = ops[i - 1]["name"]                      # the producer that was fused in (graph passes pair neighbours)
+            dw_name = ops[o["pre"] if is_pwsp else i - 1]["name"]   # the producer that was fused in (graph passes pair neighbours; pwsp names its own)
             tmax = float(taps[dw_name].abs().max())
             wmax = float(folded[o["name"]][0].abs().max())
             ulp_t = 2.0 ** (torch.floor(torch.log2(torch.tensor(tmax))).item() - 7)
@@ -197,6 +222,16 @@ def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc, want_tail=Fals
             assert float((u > 1.0 + 1e-6).float().mean()) < 0.005, (o["name"], float((u > 1.0).float().mean()))
             assert frac < 0.05, (o["name"], frac)
             nfused += 1
+            if is_pwsp:
+                # the launch also wrote the 1x1's own output when that has other readers: strict per-op contract, then the oracle's values
+                # again (this op overwrote what was teacher-forced after the stand-alone conv)
+                pre = ops[o["pre"]]
+                tp, cp0, cpc = pre["out"]
+                if o["pre_stored"]:
+                    gp = eng.read_tensor(tp)[..., cp0:cp0 + cpc]
+                    up = _ulps_bf16(gp, nchw_to_nhwc(taps[pre["name"]]))
+                    assert float(up.max()) <= 1.0 + 1e-6 and float((up > 0).float().mean()) < 0.02, (pre["name"], float(up.max()))
+                    eng.write_tensor(tp, cp0, nchw_to_nhwc(taps[pre["name"]]))
         else:
             u = _ulps_bf16(got, want)
             frac = float((u > 0).float().mean())
@@ -205,7 +240,7 @@ def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc, want_tail=Fals
             assert frac < 0.02, (o["name"], frac)
         eng.write_tensor(t, c0, want)    # teacher forcing
     _dump(f"perop_bf16_{variant}", [(n, k, e) for n, k, e, _ in rows])
-    print(variant, "cfg", cfg, "ops checked", len(rows), "fused dw->pw ops", nfused, "of them with the logit conv as third stage", ntail, "max ulp", max(r[2] for r in rows if r[1] != "f32"),
+    print(variant, "cfg", cfg, "ops checked", len(rows), "pwsp launches", npwsp, "fused dw->pw ops", nfused, "of them with the logit conv as third stage", ntail, "max ulp", max(r[2] for r in rows if r[1] != "f32"),
           "max differing fraction", max(r[3] for r in rows))
     eng.close()
     load_library().yp_debug_force_conv_cfg(-1)

@@ -88,6 +88,9 @@ struct Op {
     int fuse_tail = -1, tail_amax = -1;   // OP_CONV 1x1 without activation (fp32 logits): index of the dw->pw pointwise conv feeding it that can take it
                                   // on as a third stage, and of the OP_AMAX op behind it (or -1)
     bool fused6 = false;          // plan decision: dw -> pw -> this 1x1 (+ the class-max keys) run as conv_dwpw_kernel's TAIL form
+    int pw_pre = -1;              // OP_DWCONV (3x3 / 7x7, stride 1) / OP_POOL3: index of the 1x1 conv that produces its input and can run as the first stage of pwsp_kernel (graph pass)
+    bool fused7 = false;          // plan decision: that 1x1 and this spatial op run as pwsp_kernel (one workgroup per image and channel slice); the 1x1 is skipped
+    bool pw_store = false;        // fused7: the 1x1's own output has other readers and is written as well
     int lane = 0;                 // capture lane: independent head branches run on their own streams inside the hipGraph
     bool nms = false;             // OP_HEAD: conf filter + class-aware NMS (YOLOv8 / YOLO11) instead of the two-stage top-k (v10)
     int hb_box[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}}, hb_cf[3][3] = {{-1, -1, -1}, {-1, -1, -1}, {-1, -1, -1}};   // OP_HEAD (v10): op indices of the box / coefficient branch convs per level ({0,1,2} = 3x3, 3x3, 1x1), -1 = none
@@ -369,6 +372,25 @@ struct DwPwParams {                              // fused depthwise 3x3 s1 -> po
     float* y3; int y3_stride, y3_coff; size_t y3_bytes;
     unsigned* keys;
 };
+// pointwise 1x1 -> per-channel spatial operator, one workgroup per (image, channel slice) (pwsp.hip): the small-map layers
+struct PwSpParams {
+    const void* x; int x_stride, x_coff; size_t x_bytes; int B, H, W, K;           // input view [B,H,W,K]
+    const void* w1; const float* bias1; int act1, Kpad1, C1; size_t w1_bytes;       // 1x1: packed [C1^][K]
+    void* y1; int y1_stride, y1_coff;                                              // the pointwise result's own tensor (null: not stored)
+    const void* res1; int res1_stride, res1_coff;                                   // added to the pointwise result after act1 (sp = 0 only; nullable)
+    int sp;                                                                         // 0 none, 1 depthwise 3x3, 2 depthwise 7x7, 3 SPPF's three chained 5x5 max-pools
+    int sp_c0, Csp;                                                                 // the spatial operator reads channels [sp_c0, sp_c0 + Csp) of the pointwise result
+    const void* wd; const float* biasd; int actd;                                   // depthwise: packed [k*k][Csp] bf16, bias fp32 (indexed from sp_c0)
+    const void* res; int res_stride, res_coff;                                      // added after actd (nullable)
+    void* y2; int y2_stride, y2_coff;                                              // spatial result (pool: stage s at channel offset s * Csp)
+    int dbg;                                                                        // timing ablations (tools only, results wrong): 1 no MFMAs, 2 no pixel loads, 4 no spatial stage
+};
+bool pwsp_valid(const PwSpParams& p);
+const char* pwsp_kernel_name(const PwSpParams& p);
+constexpr int PWSP_CFG = 1000;                                                       // Op::cfg of a plain 1x1 conv that runs as pwsp_kernel<NS,0> (a tuner candidate)
+hipError_t launch_pwsp(const PwSpParams& p, hipStream_t st);
+hipError_t pwsp_read_clocks(unsigned long long* out32);
+
 bool conv_dwpw_valid(const DwPwParams& p);
 const char* conv_dwpw_kernel_name(const DwPwParams& p);
 hipError_t launch_conv_dwpw(const DwPwParams& p, hipStream_t st);

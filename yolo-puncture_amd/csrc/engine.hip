@@ -534,12 +534,8 @@ static int build_graph(yp_engine& e) {
         const int sd = 8 << l;
         const View x = feat[l];
         const std::string pb = "model.23.one2one_cv2." + L, pc = "model.23.one2one_cv3." + L;
-        const int b0 = B.tensor(pb + ".0", hc2, sd), b1 = B.tensor(pb + ".1", hc2, sd), b2 = B.tensor(pb + ".2", 64, sd, true);
-        B.lane = 1 + 3 * l;                                           // box branch of level l
-        B.conv(pb + ".0", x, B.full(b0), 3, 1, ACT_SILU);
-        B.conv(pb + ".1", B.full(b0), B.full(b1), 3, 1, ACT_SILU);
-        B.conv(pb + ".2", B.full(b1), B.full(b2), 1, 1, ACT_NONE);
-        for (int j = 0; j < 3; ++j) { head.hb_box[l][j] = (int)e.ops.size() - 3 + j; head.hb_cf[l][j] = -1; }
+        // (the class branch comes first in the op list: its depthwise conv then sits right behind the level's last neck conv, whose 1x1 it
+        // can join in pwsp_kernel whether the box branch is dense or not)
         const int k0 = B.tensor(pc + ".0.0", x.C, sd), k1 = B.tensor(pc + ".0.1", hc3, sd), k2 = B.tensor(pc + ".1.0", hc3, sd),
                   k3 = B.tensor(pc + ".1.1", hc3, sd), k4 = B.tensor(pc + ".2", nc, sd, true);
         B.lane = 2 + 3 * l;                                           // class branch
@@ -556,6 +552,12 @@ static int build_graph(yp_engine& e) {
             e.ops.push_back(o);
             head.amax[l] = B.full(am);
         }
+        const int b0 = B.tensor(pb + ".0", hc2, sd), b1 = B.tensor(pb + ".1", hc2, sd), b2 = B.tensor(pb + ".2", 64, sd, true);
+        B.lane = 1 + 3 * l;                                           // box branch of level l
+        B.conv(pb + ".0", x, B.full(b0), 3, 1, ACT_SILU);
+        B.conv(pb + ".1", B.full(b0), B.full(b1), 3, 1, ACT_SILU);
+        B.conv(pb + ".2", B.full(b1), B.full(b2), 1, 1, ACT_NONE);
+        for (int j = 0; j < 3; ++j) { head.hb_box[l][j] = (int)e.ops.size() - 3 + j; head.hb_cf[l][j] = -1; }
         head.box[l] = B.full(b2);
         head.cls[l] = B.full(k4);
         if (e.desc.task == YP_TASK_SEGMENT) {
@@ -662,6 +664,24 @@ static int finish_graph_passes(yp_engine& e) {
         c2.fuse_tail = (int)i - 1;
         if (i + 1 < e.ops.size() && e.ops[i + 1].kind == OP_AMAX && e.ops[i + 1].in.t == c2.out.t) c2.tail_amax = (int)i + 1;
     }
+    // ---- 1x1 conv -> depthwise 3x3 / 7x7 (stride 1) or SPPF's pool chain on (a channel sub-range of) its output: candidates for pwsp_kernel,
+    //      one workgroup per (image, channel slice) - the small-map layers (CIB, SPPF, the P5 class branch) --------------------------------
+    for (size_t i = 0; i < e.ops.size(); ++i) {
+        Op& d = e.ops[i];
+        const bool dw = d.kind == OP_DWCONV && (d.k == 3 || d.k == 7) && d.s == 1 && d.gs == 0;
+        if (!dw && d.kind != OP_POOL3) continue;
+        int c = -1;
+        for (size_t j = i; j-- > 0;) {                               // the latest earlier op that writes what d reads
+            const Op& q = e.ops[j];
+            if (q.out.t == d.in.t && q.out.coff < d.in.coff + d.in.C && d.in.coff < q.out.coff + q.out.C) { c = (int)j; break; }
+        }
+        if (c < 0) continue;
+        const Op& pw = e.ops[c];
+        if (pw.kind != OP_CONV || pw.k != 1 || pw.s != 1 || pw.res.t >= 0 || pw.fold_up >= 0) continue;
+        if (d.in.coff < pw.out.coff || d.in.coff + d.in.C > pw.out.coff + pw.out.C) continue;      // every channel d reads comes from this conv
+        if (e.tensors[pw.out.t].f32 || e.tensors[d.out.t].f32) continue;
+        d.pw_pre = c;
+    }
     return YP_OK;
 }
 
@@ -679,6 +699,8 @@ static DwPwParams dwpw_params(const yp_engine& e, const Op& c);
 static FrontParams front_params(const yp_engine& e, const Op& o, const uint8_t* img);
 static C2fParams c2f_params(const yp_engine& e, const Op& o);
 static ScdParams scd_params(const yp_engine& e, const Op& o);
+static PwSpParams pwsp_params(const yp_engine& e, const Op& o);
+static bool views_overlap(const View& a, const View& b);
 static size_t tensor_elem_bytes(const yp_engine& e, const TensorDesc& t) { return (t.f32 || e.dtype == DT_F32) ? 4 : 2; }
 
 // ---- winners-only head (head_branch.hip): workspace layout and parameter blocks -----------------------------------------------------------------
@@ -783,7 +805,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false; e.warmed = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel", "anchor_max_level_kernel"};
-    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; o.fused5 = false; o.fused6 = false; o.sparse_box = false; o.sparse_cf = false; }
+    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; o.fused5 = false; o.fused6 = false; o.fused7 = false; o.pw_store = false; o.sparse_box = false; o.sparse_cf = false; }
     static const bool no_fold = [] { const char* v = std::getenv("YOLOP_NO_FOLD"); return v && *v == '1'; }();   // A/B switch
     for (auto& o : e.ops) {
         if (o.kind != OP_CONV || o.fold_up < 0 || e.dtype != DT_BF16 || no_fold) continue;
@@ -907,6 +929,43 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
                 }
         }
     }
+    // 1x1 -> depthwise / pool chain as pwsp_kernel (decided last: it looks at which ops still launch). The 1x1 conv is skipped, the spatial
+    // op launches the kernel; the conv's own output is written as well when anything else reads it. Not when an op that still launches
+    // sits between the two and reads the conv's output (the kernel runs at the SPATIAL op's place in the order).
+    {
+        static const bool no_pwsp = [] { const char* v = std::getenv("YOLOP_NO_PWSP"); return v && *v == '1'; }();   // A/B switch
+        for (size_t i = 0; i < e.ops.size(); ++i) {
+            Op& d = e.ops[i];
+            if (d.pw_pre < 0 || e.dtype != DT_BF16 || !e.fuse || no_pwsp || d.skip || d.fused5) continue;
+            Op& c = e.ops[d.pw_pre];
+            if (c.skip || c.fused || c.fused2 || c.fused3 || c.fused4 || c.fused6 || c.folded) continue;
+            bool between = false, other = false;
+            for (size_t j = 0; j < e.ops.size(); ++j) {
+                const Op& q = e.ops[j];
+                if (j == i || (int)j == d.pw_pre || q.skip) continue;
+                bool reads = false;
+                for (const View* v : {&q.in, &q.res}) reads |= views_overlap(*v, c.out);
+                if (q.kind == OP_HEAD)
+                    for (int l = 0; l < 3; ++l) {
+                        for (const View* v : {&q.box[l], &q.cls[l], &q.cf[l], &q.amax[l]}) reads |= views_overlap(*v, c.out);
+                        for (int which = 0; which < 2; ++which) {
+                            const int b0 = (which == 0 ? q.hb_box : q.hb_cf)[l][0];
+                            if (b0 >= 0 && (which == 0 ? q.sparse_box : q.sparse_cf)) reads |= views_overlap(e.ops[b0].in, c.out);
+                        }
+                    }
+                other |= reads;
+                if ((int)j > d.pw_pre && j < i) {
+                    between |= reads || views_overlap(q.out, c.out) || views_overlap(q.out, d.out) || views_overlap(q.out, d.res) || views_overlap(q.in, d.out) ||
+                               views_overlap(q.res, d.out);
+                }
+            }
+            if (between) continue;
+            d.fused7 = true; d.pw_store = other;
+            if (!pwsp_valid(pwsp_params(e, d))) { d.fused7 = false; d.pw_store = false; continue; }
+            c.skip = true;
+            d.kernel = pwsp_kernel_name(pwsp_params(e, d));
+        }
+    }
     // algorithmic work of the graph as it runs: an op whose work moved into a fused consumer reports nothing and launches
     // nothing; the consumer reports the FLOPs of all its stages and the bytes of what it reads and writes (the intermediates
     // never reach HBM), a conv with a folded upsample reads the low-resolution tensor instead of its upsampled copy
@@ -920,6 +979,11 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         auto wb = [&](const Op& q) { const WeightDesc& w = e.weights[q.widx]; return (double)w.cout * w.cin_g * w.k * w.k * es; };
         for (auto& o : e.ops) {
             if (o.kind == OP_DWCONV && o.fused5) { const Op& c1 = e.ops[o.scd_pre]; o.flops += c1.flops; o.bytes = vb(c1.in) + vb(o.out) + wb(c1) + wb(o); }
+            if (o.fused7) {
+                const Op& c1 = e.ops[o.pw_pre];
+                o.flops += c1.flops;
+                o.bytes = vb(c1.in) + (o.pw_store ? vb(c1.out) : 0.0) + vb(o.out) + vb(o.res) + wb(c1) + (o.kind == OP_DWCONV ? wb(o) : 0.0);
+            }
             if (o.kind != OP_CONV) continue;
             if (o.fused) { const Op& d = e.ops[o.fuse_dw]; o.flops += d.flops; o.bytes = vb(d.in) + vb(d.res) + vb(o.out) + wb(d) + wb(o); }
             else if (o.fused6) {                    // (its pointwise conv, visited before, already carries the depthwise stage's FLOPs)
@@ -1124,6 +1188,36 @@ static ScdParams scd_params(const yp_engine& e, const Op& o) {
     return p;
 }
 
+// pwsp_kernel: `o` is the spatial op of a fused pair (o.fused7) or a plain 1x1 conv that runs in the same decomposition (cfg PWSP_CFG)
+static PwSpParams pwsp_params(const yp_engine& e, const Op& o) {
+    PwSpParams p{};
+    const bool pair = o.kind != OP_CONV;
+    const Op& c1 = pair ? e.ops[o.pw_pre] : o;
+    const WeightDesc& w1 = e.weights[c1.widx];
+    const TensorDesc &ti = e.tensors[c1.in.t], &t1 = e.tensors[c1.out.t];
+    p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = c1.in.coff; p.x_bytes = ti.bytes; p.B = e.pB; p.H = ti.H; p.W = ti.W; p.K = c1.in.C;
+    p.w1 = w1.d_w; p.bias1 = w1.d_b; p.act1 = c1.act; p.Kpad1 = w1.Kpad; p.C1 = c1.out.C; p.w1_bytes = w1.mat_bytes;
+    p.dbg = conv_debug_ablation();
+    if (!pair || o.pw_store) { p.y1 = t1.ptr ? t1.ptr : (void*)1; p.y1_stride = t1.C; p.y1_coff = c1.out.coff; }
+    if (!pair) {
+        if (c1.res.t >= 0) { const TensorDesc& tr = e.tensors[c1.res.t]; p.res1 = tr.ptr ? tr.ptr : (const void*)1; p.res1_stride = tr.C; p.res1_coff = c1.res.coff; }
+        if (w1.cin_pad != c1.in.C || t1.f32 || c1.k != 1 || c1.s != 1 || c1.fold_up >= 0) p.sp = -1;      // (not this kernel's shape)
+        return p;
+    }
+    const TensorDesc& t2 = e.tensors[o.out.t];
+    p.sp = o.kind == OP_POOL3 ? 3 : (o.k == 3 ? 1 : 2);
+    p.sp_c0 = o.in.coff - c1.out.coff; p.Csp = o.in.C;
+    if (o.kind == OP_DWCONV) {
+        const WeightDesc& wd = e.weights[o.widx];
+        p.wd = wd.d_w; p.biasd = wd.d_b; p.actd = o.act;
+        if (o.res.t >= 0) { const TensorDesc& tr = e.tensors[o.res.t]; p.res = tr.ptr ? tr.ptr : (const void*)1; p.res_stride = tr.C; p.res_coff = o.res.coff; }
+        if (o.out.C != o.in.C) p.sp = -1;
+    } else if (o.out.C != 3 * o.in.C) p.sp = -1;
+    p.y2 = t2.ptr ? t2.ptr : (void*)1; p.y2_stride = t2.C; p.y2_coff = o.out.coff;
+    if (w1.cin_pad != c1.in.C || c1.in.t < 0) p.sp = -1;
+    return p;
+}
+
 static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_t st) {
     auto T = [&](const View& v) -> const TensorDesc& { return e.tensors[v.t]; };
     const int B = e.pB;
@@ -1141,6 +1235,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             if (o.fused3) return launch_frontend(front_params(e, o, a.in), st);
             if (o.fused4) return launch_c2f_fused(c2f_params(e, o), st);
             if (o.fused2) { const ConvParams q = conv_params(e, o); return launch_conv_halo_s2(q, o.cfg - 500, st); }
+            if (o.cfg == PWSP_CFG) return launch_pwsp(pwsp_params(e, o), st);
             return launch_conv(conv_params(e, o), e.dtype, st);
         case OP_CONVT: {
             const WeightDesc& w = e.weights[o.widx];
@@ -1162,6 +1257,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
         }
         case OP_DWCONV: {
             if (o.fused5) return launch_scdown_fused(scd_params(e, o), st);
+            if (o.fused7) return launch_pwsp(pwsp_params(e, o), st);
             const WeightDesc& w = e.weights[o.widx];
             const TensorDesc &ti = T(o.in), &to = T(o.out);
             DwParams p{};
@@ -1182,6 +1278,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
         }
         case OP_POOL3: {
             const TensorDesc &ti = T(o.in), &to = T(o.out);
+            if (o.fused7) return launch_pwsp(pwsp_params(e, o), st);
             PoolParams p{};
             p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.y = to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff;
             p.B = B; p.H = ti.H; p.W = ti.W; p.C = o.in.C;
@@ -1345,6 +1442,8 @@ static int autotune(yp_engine& e) {
             for (int c = 0; !no_px && c < conv_pxd_num_cfgs(); ++c) if (conv_pxd_cfg_valid(p, c)) cands.push_back(800 + c);
             static const bool no_ks = [] { const char* v = std::getenv("YOLOP_NO_KS"); return v && *v == '1'; }();     // A/B switch
             for (int c = 0; !no_ks && c < conv_ks_num_cfgs(); ++c) if (conv_ks_cfg_valid(p, c)) cands.push_back(900 + c);
+            static const bool no_ps = [] { const char* v = std::getenv("YOLOP_NO_PWSP"); return v && *v == '1'; }();     // A/B switch
+            if (!no_ps && !o.folded && p.x2_C == 0 && pwsp_valid(pwsp_params(e, o))) cands.push_back(PWSP_CFG);
             for (int cc : cands) {
                 o.cfg = cc;
                 float tmin;
@@ -1372,7 +1471,8 @@ static int autotune(yp_engine& e) {
             }
         }
         o.cfg = bestc;
-        if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
+        if (o.cfg == PWSP_CFG) o.kernel = pwsp_kernel_name(pwsp_params(e, o));
+        else if (o.kind == OP_CONV) o.kernel = conv_kernel_name(conv_params(e, o), e.dtype);
         else { p.cfg = o.cfg; o.kernel = conv_kernel_name(p, e.dtype); }
     }
     (void)hipEventDestroy(e0);
@@ -1409,12 +1509,14 @@ static bool apply_tuning(yp_engine& e, const int* cfgs, int n) {
         if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.fused6 || o.skip) continue;
         ConvParams p = tune_params(e, o);
         p.cfg = -1;
+        if (cfgs[i] == PWSP_CFG) { if (o.kind != OP_CONV || o.folded || !pwsp_valid(pwsp_params(e, o))) return false; continue; }
         if (!conv_cfg_usable(p, e.dtype, cfgs[i])) return false;
     }
     for (size_t i = 0; i < e.ops.size(); ++i) {
         Op& o = e.ops[i];
         if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.fused6 || o.skip) continue;   // a fused op keeps its own symbol / id
         o.cfg = cfgs[i];
+        if (o.cfg == PWSP_CFG) { o.kernel = pwsp_kernel_name(pwsp_params(e, o)); continue; }
         ConvParams p = tune_params(e, o);
         p.cfg = o.cfg;
         o.kernel = conv_kernel_name(p, e.dtype);
@@ -1506,6 +1608,7 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     if (o.fused) rd.push_back(e.ops[o.fuse_dw].in);
     else if (o.fused6) rd.push_back(e.ops[e.ops[o.fuse_tail].fuse_dw].in);
     else if (o.fused5) rd.push_back(e.ops[o.scd_pre].in);
+    else if (o.fused7) rd.push_back(e.ops[o.pw_pre].in);
     else if (o.fused4) rd.push_back(View{o.in.t, o.in.coff, 2 * e.ops[o.c2f_m1].in.C});
     else if (o.fused3) { /* reads the caller's frames only */ }
     else if (o.fused2) rd.push_back(e.ops[o.fuse_pre].in);
@@ -1513,6 +1616,7 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     if (o.folded) rd.push_back(e.ops[o.fold_up].in);      // (besides the concat buffer, whose skip part it still reads)
     if (o.res.t >= 0) rd.push_back(o.res);
     if (o.out.t >= 0) wr.push_back(o.out);
+    if (o.fused7 && o.pw_store) wr.push_back(e.ops[o.pw_pre].out);
     if (o.fused6 && o.tail_amax >= 0) wr.push_back(e.ops[o.tail_amax].out);
     if (o.kind == OP_HEAD)
         for (int l = 0; l < 3; ++l) {
@@ -1939,6 +2043,14 @@ int yp_op_kernel(const yp_engine* e, int i, char* name, int cap) {
     return YP_OK;
 }
 
+int yp_op_fusion(const yp_engine* e, int i, int* pre, int* pre_stored) {
+    if (!e || i < 0 || i >= (int)e->ops.size()) return fail(YP_ERR_ARG, "bad op index");
+    const Op& o = e->ops[i];
+    if (pre) *pre = o.fused7 ? o.pw_pre : -1;
+    if (pre_stored) *pre_stored = (o.fused7 && o.pw_store) ? 1 : 0;
+    return YP_OK;
+}
+
 int yp_op_output(const yp_engine* e, int i, int* tensor, int* coff, int* C) {
     if (!e || i < 0 || i >= (int)e->ops.size()) return fail(YP_ERR_ARG, "bad op index");
     const Op& o = e->ops[i];
@@ -2296,6 +2408,13 @@ int yp_debug_marker(void* stream) {
     return YP_OK;
 }
 
+int yp_debug_pwsp_clocks(uint64_t* out32) {
+    if (!out32) return fail(YP_ERR_ARG, "yp_debug_pwsp_clocks: null output");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(pwsp_read_clocks((unsigned long long*)out32));
+    return YP_OK;
+}
+
 int yp_debug_contour_clocks(uint64_t* out12) {
     if (!out12) return fail(YP_ERR_ARG, "yp_debug_contour_clocks: null output");
     HIPCHK(hipDeviceSynchronize());
@@ -2335,6 +2454,7 @@ int yp_debug_host_selftest(yp_engine* e) {
             else if (o.fused4) acc += (size_t)c2f_params(*e, o).Cout;
             else acc += (size_t)conv_params(*e, o).Cout;
         } else if (o.kind == OP_DWCONV && o.fused5) acc += (size_t)scd_params(*e, o).C;
+        else if (o.fused7) acc += (size_t)pwsp_params(*e, o).C1;
     }
     finish_kernel_names(*e);
     save_tune_cache(*e);

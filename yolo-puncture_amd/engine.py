@@ -60,6 +60,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_op_info.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, ip, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.yp_op_output.argtypes = [vp, C.c_int, ip, ip, ip]
     lib.yp_op_kernel.argtypes = [vp, C.c_int, C.c_char_p, C.c_int]
+    lib.yp_op_fusion.argtypes = [vp, C.c_int, ip, ip]
+    lib.yp_op_fusion.restype = C.c_int
     lib.yp_run_op.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     lib.yp_tensor_write.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp]
     lib.yp_tensor_count.argtypes = [vp]
@@ -83,6 +85,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_debug_head_clocks.argtypes = [C.POINTER(C.c_uint64)]
     lib.yp_debug_head_branch_clocks.argtypes = [C.POINTER(C.c_uint64)]
     lib.yp_debug_contour_clocks.argtypes = [C.POINTER(C.c_uint64)]
+    lib.yp_debug_pwsp_clocks.argtypes = [C.POINTER(C.c_uint64)]
     lib.yp_letterbox.argtypes = [vp, C.c_int, C.c_int, vp] + [C.c_int] * 7 + [vp]
     lib.yp_letterbox.restype = C.c_int
     lib.yp_comm_unique_id.argtypes = [vp]
@@ -102,9 +105,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 
 
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
-           "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output", "yp_op_input",
+           "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output", "yp_op_input", "yp_op_fusion",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_tuning_export", "yp_tuning_import", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_head_branch_clocks", "yp_debug_head_winners", "yp_debug_contour_clocks", "yp_debug_host_selftest", "yp_debug_graph_info", "yp_debug_head_positions", "yp_debug_marker", "yp_letterbox", "yp_mask_contours",
+           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_tuning_export", "yp_tuning_import", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_head_branch_clocks", "yp_debug_head_winners", "yp_debug_contour_clocks", "yp_debug_pwsp_clocks", "yp_debug_host_selftest", "yp_debug_graph_info", "yp_debug_head_positions", "yp_debug_marker", "yp_letterbox", "yp_mask_contours",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy",
            "yp_u2net_create", "yp_u2net_destroy", "yp_u2net_weight_count", "yp_u2net_weight_info", "yp_u2net_set_weight", "yp_u2net_finalize",
            "yp_u2net_forward", "yp_u2net_set_graph", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
@@ -365,6 +368,9 @@ class Engine:
             self._chk(self.lib.yp_op_input(self._h, i, C.byref(t), C.byref(co), C.byref(cc), C.byref(cr)))
             rec["in"] = (t.value, co.value, cc.value)
             rec["c_read"] = cr.value
+            pre, stored = C.c_int(), C.c_int()
+            self._chk(self.lib.yp_op_fusion(self._h, i, C.byref(pre), C.byref(stored)))
+            rec["pre"], rec["pre_stored"] = pre.value, bool(stored.value)     # pwsp_kernel: the 1x1 conv fused in front (or -1), and whether its output is written too
             ops.append(rec)
         return ops
 
