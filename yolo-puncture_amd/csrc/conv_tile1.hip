@@ -257,6 +257,190 @@ __global__ __launch_bounds__(512) void conv_tile1_kernel(const ConvParams p, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Wide-wave-tile form (configuration 2, round 4): the same one-tile-per-CU problem with the roles split. PMC and the in-kernel stamps put
+// conv_tile1's main loop at 20.7 k cycles of LDS fragment reads against 16.1 k of MFMA per CU and layer (a wave tile of 7 pixel x 2 channel
+// fragments reads 9 fragments per 14 MFMAs), plus a ~300-cycle issue stall per weight piece inside the consumers. Here
+//   * waves 0-3 (one per SIMD) are CONSUMERS with 7 x 4 fragment tiles - 112 pixels x 64 output channels, 11 fragment reads per 28 MFMAs:
+//     44 KB instead of 72 KB of LDS reads per tap and CU, below the 448 cycles the tap's MFMAs take;
+//   * waves 4-7 (one per SIMD) are LOADERS: they issue the patch planes and the weight ring's pieces (6 per wave and stage) and nothing
+//     else, so no consumer ever waits on a DMA issue slot;
+//   * one workgroup barrier per stage (tap row) hands a landed stage to the consumers and a finished slot back to the loaders.
+template <int FMW, bool HAS_RES, bool OUT_F32>
+__global__ __launch_bounds__(512) void conv_tile1w_kernel(const ConvParams p, const Tile1Geo g) {
+    constexpr int BN = 128, FN = 4, FM = FMW;
+    static_assert(FMW == T1_FMX, "geometry");
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int nchunk = p.Cin >> 5;
+    unsigned char* const Xs = smem;                                        // [nchunk][ppc*16 px][32 ch]
+    unsigned char* const Ws = smem + (size_t)nchunk * g.ppc * 1024;       // [NS][3 taps][BN][32 ch]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fc = lane >> 4;
+    int t = blockIdx.x;                                                     // (BN = Cout tile: launched only for Cout <= 128)
+    const int tw = t % g.tiles_w; t /= g.tiles_w;
+    const int th = t % g.tiles_h;
+    const int b = t / g.tiles_h;
+    const int r0 = th * g.TR, c0 = tw * g.TC;
+    const int HC = g.TC + 2;
+    const int nst = nchunk * 3;
+    constexpr int SW = 3 * BN * 64;                                         // bytes per stage: 24 pieces
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.y, 0, (int)p.y_bytes, 0x00020000);
+
+    if (wave >= 4) {
+        // ================================================= loaders =================================================
+        const int lw = wave - 4;
+        // patch plane ch: ppc pieces of 16 pixels, dealt round the four loader waves; every loader issues the same NUMBER of instructions
+        // per plane (the surplus ones read out of range into the plane's padding rows), so that the counted waits below hold for all
+        const int xpw = (g.ppc + 3) >> 2;
+        auto issue_x = [&](int ch) {
+            const int HR = g.TR + 2, npx = HR * HC;
+            for (int j = 0; j < xpw; ++j) {
+                const int pi = min(lw + 4 * j, g.ppc - 1);              // (a surplus instruction rewrites the plane's last piece with the same bytes)
+                const int hp = pi * 16 + (lane >> 2), pc = lane & 3;
+                const int c8 = pc ^ tswz(hp);
+                const int hy = hp / HC, hx = hp - hy * HC;
+                const int hi = r0 - 1 + hy, wi = c0 - 1 + hx;
+                const bool ok = hp < npx && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                const unsigned voff = ok ? (unsigned)((((b * p.H + hi) * p.W + wi) * p.x_stride + p.x_coff + ch * 32 + c8 * 8) * 2) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(Xs + (ch * g.ppc + pi) * 1024), 16, voff, 0, 0, 0);
+            }
+        };
+        unsigned wbase[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int q = lw + 4 * j;                                       // piece of the stage: tap kx = q / 8, rows (q % 8) * 16 ..
+            const int kx = q >> 3, n = (q & 7) * 16 + (lane >> 2), pc = lane & 3;
+            const int c8 = pc ^ tswz(n);
+            wbase[j] = (unsigned)((n * p.Kpad + kx * p.Cin + c8 * 8) * 2);
+        }
+        auto issue_stage = [&](int stage) {
+            const int ch = stage / 3, ky = stage - ch * 3;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const unsigned voff = (stage < nst) ? wbase[j] + (unsigned)((ky * 3 * p.Cin + ch * 32) * 2) : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)(Ws + (stage % T1_NS) * SW + (lw + 4 * j) * 1024), 16, voff, 0, 0, 0);
+            }
+        };
+        // issue order: X0 W0 W1 | (stage 0 barrier) X1 W2 | (stage 1) W3 | (stage 2) W4 | (stage 3) X2 W5 | ...
+        issue_x(0);
+        issue_stage(0);
+        issue_stage(1);
+        for (int st = 0; st < nst; ++st) {
+            // stage st (and every plane issued before it) has landed once at most the 6 pieces of stage st + 1 are in flight
+            wait_vt1<6>();
+            __builtin_amdgcn_s_barrier();
+            const int ch = st / 3, ky = st - ch * 3;
+            if (ky == 0 && ch + 1 < nchunk) issue_x(ch + 1);                // lands two stages before its first use: the wait above covers it (in-order counter)
+            issue_stage(st + 2);                                            // slot of stage st - 1: every consumer passed this barrier, so it is done with it
+        }
+        wait_vt1<0>();
+        return;
+    }
+
+    // ================================================= consumers =================================================
+    const int wm = wave & 1, wn = wave >> 1;
+    float bias[FN][4];
+#pragma unroll
+    for (int a = 0; a < FN; ++a) {
+        const int co = wn * (FN * 16) + a * 16 + fc * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias[a][r] = (co + r < p.Cout) ? p.bias[co + r] : 0.f;
+    }
+    const int npix = g.TR * g.TC;
+    const int per_wave = (g.nfr + 1) >> 1;
+    const int f0 = wm * per_wave;
+    unsigned lbase[FM];
+#pragma unroll
+    for (int f = 0; f < FM; ++f) {
+        int pp = (f0 + f) * 16 + fr;
+        if (pp >= npix) pp = npix - 1;
+        const int r = pp / g.TC, c = pp - r * g.TC;
+        lbase[f] = (unsigned)((r * HC + c) * 64 + fc * 16);
+    }
+    unsigned wl[3][FN];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int rw = kx * BN + wn * (FN * 16) + a * 16 + fr;
+            wl[kx][a] = (unsigned)(rw * 64 + ((fc ^ tswz(rw)) * 16));
+        }
+    const int myf = max(0, min(per_wave, g.nfr - f0));
+    f32x4 acc[FN][FM];
+#pragma unroll
+    for (int a = 0; a < FN; ++a)
+#pragma unroll
+        for (int f = 0; f < FM; ++f) acc[a][f] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};
+
+    bf16x8 xf[2][FM], wf[2][FN];
+    auto read_x = [&](bf16x8 (&dst)[FM], int stage, int kx) {
+        const int ch = stage / 3, ky = stage - ch * 3;
+        const unsigned char* xs = Xs + (size_t)ch * g.ppc * 1024;
+        const unsigned tapb = (unsigned)((ky * HC + kx) * 64);
+#pragma unroll
+        for (int f = 0; f < FM; ++f) {
+            const unsigned L = lbase[f] + tapb;
+            dst[f] = *(const bf16x8*)(xs + (L ^ ((L >> 3) & 32u)));
+        }
+    };
+    auto read_w = [&](bf16x8 (&dst)[FN], int stage, int kx) {
+        const unsigned char* ws = Ws + (stage % T1_NS) * SW;
+#pragma unroll
+        for (int a = 0; a < FN; ++a) dst[a] = *(const bf16x8*)(ws + wl[kx][a]);
+    };
+    // software pipeline by one tap across the whole loop; the first tap of a stage can only be read behind that stage's barrier
+    for (int st = 0; st < nst; ++st) {
+        __builtin_amdgcn_s_barrier();
+        read_w(wf[0], st, 0);
+        read_x(xf[0], st, 0);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int cur = kx & 1, nxt = cur ^ 1;
+            if (kx < 2) { read_w(wf[nxt], st, kx + 1); read_x(xf[nxt], st, kx + 1); }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int f = 0; f < FM; ++f)
+#pragma unroll
+                for (int a = 0; a < FN; ++a) acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][a], xf[cur][f], acc[a][f], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+#pragma unroll
+    for (int f = 0; f < FM; ++f) {
+        if (f >= myf) continue;
+        const int pp = (f0 + f) * 16 + fr;
+        const int r = pp / g.TC, c = pp - r * g.TC;
+        const int ho = r0 + r, wo = c0 + c;
+        const bool pix_ok = pp < npix && ho < p.Ho && wo < p.Wo;
+        const unsigned m = (unsigned)((b * p.Ho + ho) * p.Wo + wo);
+#pragma unroll
+        for (int a = 0; a < FN; ++a) {
+            const int co = wn * (FN * 16) + a * 16 + fc * 4;
+            const bool ok = pix_ok && co < p.Cout;
+            float v[4] = {acc[a][f][0], acc[a][f][1], acc[a][f][2], acc[a][f][3]};
+            if (p.act == ACT_SILU) silu4_packed(v);
+            if (HAS_RES) {
+                const uint2 rr = ok ? *(const uint2*)((const __bf16*)p.res + (size_t)m * p.res_stride + p.res_coff + co) : make_uint2(0u, 0u);
+                v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+                v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+            }
+            if (OUT_F32) {
+                const unsigned off = ok ? (m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 4u : OOB;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, make_float4(v[0], v[1], v[2], v[3])), yrs, off, 0, 0);
+            } else {
+                const unsigned off = ok ? (m * (unsigned)p.y_stride + (unsigned)(p.y_coff + co)) * 2u : OOB;
+                __attribute__((aligned(8))) __bf16 o[4] = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+                __builtin_amdgcn_raw_buffer_store_b64(*(const __attribute__((ext_vector_type(2))) unsigned*)o, yrs, off, 0, 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // host: pick TR x TC so that the whole problem is one round of at most 256 workgroups
 static bool tile1_geometry(const ConvParams& p, int BN, Tile1Geo& g, size_t& lds) {
     const int WGM = 8 / (BN / 32);
@@ -283,17 +467,18 @@ static bool tile1_geometry(const ConvParams& p, int BN, Tile1Geo& g, size_t& lds
     return found;
 }
 
-int conv_tile1_num_cfgs() { return 2; }
-const char* conv_tile1_kernel_name(int c) { return c == 0 ? "conv_tile1_kernel<4>" : "conv_tile1_kernel<2>"; }
+int conv_tile1_num_cfgs() { return 3; }
+const char* conv_tile1_kernel_name(int c) { return c == 0 ? "conv_tile1_kernel<4>" : c == 1 ? "conv_tile1_kernel<2>" : "conv_tile1w_kernel<7>"; }
 
 bool conv_tile1_cfg_valid(const ConvParams& p, int c) {
-    if (c < 0 || c >= 2) return false;
+    if (c < 0 || c >= 3) return false;
     if (p.ks != 3 || p.stride != 1 || p.pad != 1 || p.up != 1 || (p.Cin % 32) != 0 || p.Kpad != 9 * p.Cin || p.x2_C > 0) return false;
     if (p.x_bytes >= (1ull << 31) || p.w_bytes >= (1ull << 31) || p.y_bytes >= (1ull << 31)) return false;
     if ((p.Cout & 3) || (p.y_stride & 3) || (p.y_coff & 3) || (p.res && ((p.res_stride & 3) || (p.res_coff & 3)))) return false;
     if (p.res && p.out_f32) return false;
-    const int BN = c == 0 ? 128 : 64;
+    const int BN = c == 1 ? 64 : 128;
     if (BN > (p.Cout + 31) / 32 * 32) return false;
+    if (c == 2 && p.Cout > 128) return false;                // (the wide form has no output-channel tiling)
     Tile1Geo g;
     size_t lds;
     if (!tile1_geometry(p, BN, g, lds)) return false;
@@ -338,7 +523,30 @@ static hipError_t launch_tile1_var(const ConvParams& p, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <bool HAS_RES, bool OUT_F32>
+static hipError_t launch_tile1w_var(const ConvParams& p, hipStream_t st) {
+    Tile1Geo g;
+    size_t sh;
+    if (!tile1_geometry(p, 128, g, sh)) return hipErrorInvalidValue;
+    const int B = p.M / (p.Ho * p.Wo);
+    const int tiles = B * g.tiles_h * g.tiles_w;
+    auto kern = conv_tile1w_kernel<T1_FMX, HAS_RES, OUT_F32>;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024));
+        if (e != hipSuccess) return e;
+        attr = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(tiles), dim3(512), sh, st, p, g);
+    return hipGetLastError();
+}
+
 hipError_t launch_conv_tile1(const ConvParams& p, int c, hipStream_t st) {
+    if (c == 2) {
+        if (p.out_f32) return launch_tile1w_var<false, true>(p, st);
+        if (p.res) return launch_tile1w_var<true, false>(p, st);
+        return launch_tile1w_var<false, false>(p, st);
+    }
     if (c == 0) {
         if (p.out_f32) return launch_tile1_var<4, false, true>(p, st);
         if (p.res) return launch_tile1_var<4, true, false>(p, st);

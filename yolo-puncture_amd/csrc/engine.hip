@@ -1578,7 +1578,7 @@ static DwPwParams dwpw_params(const yp_engine& e, const Op& c) {
 // the persistent conv kernels are additionally templated on <HAS_RES, OUT_F32>: make the reported symbol exact
 static void finish_kernel_names(yp_engine& e) {
     for (Op& o : e.ops) {
-        const bool lc = o.kernel.find("_lc_kernel<") != std::string::npos || o.kernel.find("_s2_kernel<") != std::string::npos || o.kernel.find("_tile1_kernel<") != std::string::npos || o.kernel.find("_wreg_kernel<") != std::string::npos || o.kernel.find("_pxd_kernel<") != std::string::npos || o.kernel.find("_ks_kernel<") != std::string::npos;
+        const bool lc = o.kernel.find("_lc_kernel<") != std::string::npos || o.kernel.find("_s2_kernel<") != std::string::npos || o.kernel.find("_tile1_kernel<") != std::string::npos || o.kernel.find("_tile1w_kernel<") != std::string::npos || o.kernel.find("_wreg_kernel<") != std::string::npos || o.kernel.find("_pxd_kernel<") != std::string::npos || o.kernel.find("_ks_kernel<") != std::string::npos;
         if ((o.kernel.find("_p_kernel<") == std::string::npos && !lc) || o.kernel.find(",false>") != std::string::npos || o.kernel.find(",true>") != std::string::npos) continue;
         const bool f32 = (o.kind == OP_CONV) && e.tensors[o.out.t].f32 && e.dtype == DT_BF16;
         const bool res = o.res.t >= 0;
