@@ -375,39 +375,49 @@ __global__ __launch_bounds__(512) void conv_tile1w_kernel(const ConvParams p, co
 #pragma unroll
         for (int f = 0; f < FM; ++f) acc[a][f] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};
 
+    // Fragment reads are inline-asm ds_read_b128 with COUNTED lgkmcnt waits. Left to the compiler, the wait in front of a tap's MFMAs was
+    // lgkmcnt(0): it also waited for the next tap's reads, issued just before - the software pipeline did not overlap anything (ablations
+    // on the first form of this kernel: 8.5 us of MFMA and 6.3 us of fragment reads both fully exposed in a 28.6-us launch).
     bf16x8 xf[2][FM], wf[2][FN];
-    auto read_x = [&](bf16x8 (&dst)[FM], int stage, int kx) {
+    const unsigned xs_l = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Xs;
+    const unsigned ws_l = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)Ws;
+    auto lds_rd = [](bf16x8& dst, unsigned addr) { asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr)); };
+    auto read_tap = [&](bf16x8 (&xd)[FM], bf16x8 (&wd)[FN], int stage, int kx) {       // 4 + 7 = 11 reads
         const int ch = stage / 3, ky = stage - ch * 3;
-        const unsigned char* xs = Xs + (size_t)ch * g.ppc * 1024;
+        const unsigned wsb = ws_l + (unsigned)((stage % T1_NS) * SW);
+#pragma unroll
+        for (int a = 0; a < FN; ++a) lds_rd(wd[a], wsb + wl[kx][a]);
+        const unsigned xsb = xs_l + (unsigned)(ch * g.ppc * 1024);
         const unsigned tapb = (unsigned)((ky * HC + kx) * 64);
 #pragma unroll
         for (int f = 0; f < FM; ++f) {
             const unsigned L = lbase[f] + tapb;
-            dst[f] = *(const bf16x8*)(xs + (L ^ ((L >> 3) & 32u)));
+            lds_rd(xd[f], xsb + (L ^ ((L >> 3) & 32u)));
         }
     };
-    auto read_w = [&](bf16x8 (&dst)[FN], int stage, int kx) {
-        const unsigned char* ws = Ws + (stage % T1_NS) * SW;
+    static_assert(FM == 7 && FN == 4, "operand lists of the waits");
+    // the set (xs, ws) has landed once at most `N` younger reads are outstanding; the registers pass through the wait, so no use moves above it
+#define T1W_WAIT(N, xs_, ws_) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(xs_[0]), "+v"(xs_[1]), "+v"(xs_[2]), "+v"(xs_[3]), "+v"(xs_[4]), "+v"(xs_[5]), "+v"(xs_[6]), \
+                                           "+v"(ws_[0]), "+v"(ws_[1]), "+v"(ws_[2]), "+v"(ws_[3]) : : "memory")
+    auto mfma_tap = [&](bf16x8 (&xd)[FM], bf16x8 (&wd)[FN]) {
 #pragma unroll
-        for (int a = 0; a < FN; ++a) dst[a] = *(const bf16x8*)(ws + wl[kx][a]);
+        for (int f = 0; f < FM; ++f)
+#pragma unroll
+            for (int a = 0; a < FN; ++a) acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wd[a], xd[f], acc[a][f], 0, 0, 0);
     };
-    // software pipeline by one tap across the whole loop; the first tap of a stage can only be read behind that stage's barrier
     for (int st = 0; st < nst; ++st) {
         __builtin_amdgcn_s_barrier();
-        read_w(wf[0], st, 0);
-        read_x(xf[0], st, 0);
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int cur = kx & 1, nxt = cur ^ 1;
-            if (kx < 2) { read_w(wf[nxt], st, kx + 1); read_x(xf[nxt], st, kx + 1); }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int f = 0; f < FM; ++f)
-#pragma unroll
-                for (int a = 0; a < FN; ++a) acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[cur][a], xf[cur][f], acc[a][f], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        read_tap(xf[0], wf[0], st, 0);
+        read_tap(xf[1], wf[1], st, 1);
+        T1W_WAIT(11, xf[0], wf[0]);
+        mfma_tap(xf[0], wf[0]);
+        read_tap(xf[0], wf[0], st, 2);              // (in-order issue: behind the MFMAs that read set 0)
+        T1W_WAIT(11, xf[1], wf[1]);
+        mfma_tap(xf[1], wf[1]);
+        T1W_WAIT(0, xf[0], wf[0]);
+        mfma_tap(xf[0], wf[0]);
     }
+#undef T1W_WAIT
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int f = 0; f < FM; ++f) {
