@@ -15,7 +15,7 @@ B, S = 32, 640
 st = synthetic_state("s", 80, False, seed=0)
 frames = torch.randint(0, 256, (B, S, S, 3), dtype=torch.uint8).to(dev)
 engs, cfgs = [], None
-for i in range(2):
+for i in range(3):
     e = Engine("s", 80, False, "bf16", 0, state=st)
     if cfgs is not None:
         e.tuning_import(B, S, S, cfgs)
@@ -24,7 +24,7 @@ for i in range(2):
     if cfgs is None:
         cfgs = e.tuning_export()
     engs.append(e)
-outs = [dict(det=torch.empty((B, 300, 6), device=dev), idx=torch.empty((B, 300), dtype=torch.int32, device=dev), coeff=None) for _ in range(2)]
+outs = [dict(det=torch.empty((B, 300, 6), device=dev), idx=torch.empty((B, 300), dtype=torch.int32, device=dev), coeff=None) for _ in range(3)]
 
 
 def measure(tag, streams, mode):
@@ -54,3 +54,9 @@ measure("two in flight, chains, default + high priority", [s_def[0], s_hi[0]], 2
 measure("two in flight, chains, high + high priority", [s_hi[0], s_hi[1]], 2)
 measure("two in flight, lanes, default + high priority", [s_def[0], s_hi[0]], 1)
 measure("two in flight, lanes, default 0 and 1", [s_def[0], s_def[1]], 1)
+print("priority range:", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "n/a")
+for k in (1, 2, 3, 4):
+    measure(f"three in flight, chains, default 0 + high 0 + default {k}", [s_def[0], s_hi[0], s_def[k]], 2)
+measure("three in flight, chains, default 0 + high 0 + high 1", [s_def[0], s_hi[0], s_hi[1]], 2)
+measure("three in flight, chains, default 0, 2, 3", [s_def[0], s_def[2], s_def[3]], 2)
+measure("two in flight again, default + high", [s_def[0], s_hi[0]], 2)
