@@ -1236,6 +1236,10 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             if (o.fused4) return launch_c2f_fused(c2f_params(e, o), st);
             if (o.fused2) { const ConvParams q = conv_params(e, o); return launch_conv_halo_s2(q, o.cfg - 500, st); }
             if (o.cfg == PWSP_CFG) return launch_pwsp(pwsp_params(e, o), st);
+            if (conv_dma_forced_cfg() == PWSP_CFG && e.dtype == DT_BF16 && !o.folded) {          // test hook (yp_debug_force_conv_cfg): every 1x1 that admits it
+                const PwSpParams q = pwsp_params(e, o);
+                if (q.sp == 0 && pwsp_valid(q)) return launch_pwsp(q, st);
+            }
             return launch_conv(conv_params(e, o), e.dtype, st);
         case OP_CONVT: {
             const WeightDesc& w = e.weights[o.widx];
