@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Idle time inside replayed steps, from a rocprofv3 --kernel-trace csv of bench.py: for the last K steps (a step = one run of
-kernels between two head_select launches) print the wall span, the union of kernel busy intervals, the idle remainder and the
+kernels up to the top-k's last kernel) print the wall span, the union of kernel busy intervals, the idle remainder and the
 gaps by size; also the concurrency-weighted busy time (sum of durations).
 usage: python3 tools/graph_gaps.py DIR [steps]"""
 import csv, glob, sys
@@ -9,7 +9,7 @@ K = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 f = sorted(glob.glob(f"{d}/**/*kernel_trace.csv", recursive=True))[0]
 rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
 rows.sort()
-ends = [i for i, r in enumerate(rows) if "head_select" in r[2] or "head_nms_kernel" in r[2]]
+ends = [i for i, r in enumerate(rows) if "head_select_kernel<2>" in r[2] or "head_select_kernel<0>" in r[2] or "head_nms_kernel" in r[2]]   # the last kernel of a step
 ends = ends[-(K + 1):]
 tot_span = tot_busy = tot_sum = 0
 gaps = []
