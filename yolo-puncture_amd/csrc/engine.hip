@@ -1487,7 +1487,7 @@ static int autotune(yp_engine& e) {
 
 // Optional on-disk cache of the autotuner's choices (env YOLOP_TUNE_CACHE=<path prefix>): one file per
 // (variant, task, dtype, B, H, W), lines "<op name> <cfg>". Lets a profiled run skip the tuning launches.
-static const int TUNE_TABLE_VERSION = 3;
+static const int TUNE_TABLE_VERSION = 4;
 static std::string tune_cache_path(const yp_engine& e) {
     const char* pre = std::getenv("YOLOP_TUNE_CACHE");
     if (!pre || !*pre) return "";
