@@ -8,9 +8,9 @@
 // Depthwise and pooling operators mix pixels but not channels, a 1x1 convolution mixes channels but not pixels. A workgroup that owns ALL
 // pixels of one image and a SLICE of the output channels can therefore run the 1x1 GEMM for its slice and then the spatial operator on
 // its own result, which never leaves the chip:
-//   GEMM     C[HW px][NS ch] = X[HW][K] * W[NS][K]^T; the pixel operand goes global -> registers in MFMA fragment layout (in NHWC a pixel
-//            row IS the k-contiguous B-fragment row: conv_pxd.hip), every one of the 16 waves owns up to two 16-pixel fragments and all NS/16
-//            channel fragments; the [NS][64] weight block of a k-step travels by LDS-DMA through a 3-slot ring shared by the waves.
+//   GEMM     C[HW px][NS ch] = X[HW][K] * W[NS][K]^T; both operands travel by LDS-DMA in whole 128-byte lines (8 pixel rows x 64 channels per
+//            1-KiB piece) through rings shared by the 16 waves - two slots each for the pixel rows of fragments 0..15 and 16..31, three for
+//            the [NS][64] weight block of a k-step -, every wave owns up to two 16-pixel fragments and all NS/16 channel fragments.
 //            Ingest per workgroup: HW*K*2 B of pixels (through L2: the NS-slices of an image run on the same XCD) + NS*K*2 B of weights.
 //   epilogue bias + SiLU + bf16 -> (optionally) the pointwise result's own tensor in HBM, and an NHWC image of the slice in LDS with a
 //            zero halo;
@@ -87,20 +87,16 @@ __global__ __launch_bounds__(PS_NT) void pwsp_kernel(const PwSpParams p) {
     const int n0 = sl * NS;
     const bool spatial = SP != 0 && n0 >= p.sp_c0 && n0 + NS <= p.sp_c0 + p.Csp;
     const int nk = (p.Kpad1 + BK - 1) / BK;
-    // The slices of an image walk the same pixel rows. Started at the same k they request the same cache lines from the same L2 channel at
-    // the same time (measured: 19 B/clk/CU of ingest against ~32 elsewhere); slice s therefore starts its K loop s * nk / nsl steps further on
-    // and wraps round. A channel's fp32 sum is taken in its slice's order whatever the image or its place in the batch.
-    const int rot = static_cast<int>(((long)sl * nk) / nsl) % nk;
-
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w1, 0, (int)p.w1_bytes, 0x00020000);
 
-    // ---- the LDS image (whole output patches + halo) starts as zeros: the depthwise padding --------------------------------------------
+    // the spatial stage's image in LDS: whole output patches + halo
     const int dgx = (p.W + DW_PW - 1) / DW_PW, dgy = (p.H + DW_PH - 1) / DW_PH;
     const int IW = (SP == 1 || SP == 2) ? dgx * DW_PW + 2 * PAD : p.W, IH = (SP == 1 || SP == 2) ? dgy * DW_PH + 2 * PAD : p.H;
     // ---- GEMM: BOTH operands by LDS-DMA in whole 128-byte lines ---------------------------------------------------------------------------
     // (first form of this kernel: the pixel operand global -> registers in fragment layout as conv_pxd does. A fragment's 16 lanes of a quad
     //  group are 16 different pixel rows, 64 bytes of each per instruction - half-used cache lines: 19 B/clk/CU of ingest, 3.3 k cycles per
-    //  k-step of 64 KB whatever the number of issuing waves (8 or 16), unchanged with the MFMAs removed. A DMA piece is 8 rows x 128 B.)
+    //  k-step of 64 KB whatever the number of issuing waves (8 or 16), unchanged with the MFMAs removed or with the slices of an image started
+    //  at different k. A DMA piece is 8 rows x 128 B.)
     // Stages: A_g = weight block of k-step g + the pixel rows of fragments 0..15, B_g = the pixel rows of fragments 16... Two slots each for
     // A and B pixels, three for the weights (B_g still reads block g while A_g+2 is issued). Per wave and stage 3 (A) / 2 (B) pieces,
     // issued whether they exist or not (the rest go to a dump slot with an out-of-range source), so that one counted wait fits every step:
@@ -129,7 +125,7 @@ __global__ __launch_bounds__(PS_NT) void pwsp_kernel(const PwSpParams p) {
         const int c = pc ^ ((row >> 1) & 7);
         wconst = (wave < W_INSTR) ? (unsigned)(((n0 + row) * p.Kpad1 + c * 8) * 2) : OOB;
     }
-    auto kbyte = [&](int kt) { return (unsigned)((kt + rot < nk ? kt + rot : kt + rot - nk) * BK) * 2u; };
+    auto kbyte = [&](int kt) { return (unsigned)(kt * BK) * 2u; };
     auto issue_A = [&](int kt) {
         const bool live = kt < nk;
         const unsigned kb = kbyte(kt);
