@@ -140,7 +140,7 @@ def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc, want_tail=Fals
     rows = []
     from yolo_puncture_amd.weights import fold_state
     folded = fold_state(st)
-    nfused = ntail = npwsp = 0
+    nfused = ntail = npwsp = nclsout = 0
     for i, o in enumerate(ops):
         if o["kind"] == "head":
             continue
@@ -199,6 +199,13 @@ def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc, want_tail=Fals
             err = rel_err(got, want)
             rows.append((o["name"], o["kind"], err, 0.0))
             assert err < 2e-5, (o["name"], err)
+            if str(o.get("kernel", "")).startswith("cls_out_kernel"):
+                # the same launch wrote the class-max keys (the OP_AMAX op is skipped): bits of sigmoid(max_c logit) of ITS logits
+                am = [q for q in ops if q["name"] == o["name"].replace("one2one_cv3", "amax").rsplit(".", 1)[0]]
+                assert am and am[0]["kernel"] == "-", (o["name"], am)
+                keys = eng.read_tensor(am[0]["out"][0])[..., 0]
+                assert float((keys - torch.sigmoid(got.max(-1).values)).abs().max()) < 2e-7, o["name"]
+                nclsout += 1
         elif str(o.get("kernel", "")).startswith(("conv_dwpw", "frontend_kernel", "c2f_fused_kernel", "scdown_fused_kernel")) or is_pwsp or \
                 (str(o.get("kernel", "")).endswith(",false,false,true>") and "halo_s2" in str(o.get("kernel", ""))) or \
                 (o["kernel"] == "-" and o["kind"] == "conv" and i + 1 < len(ops) and ",tail," in str(ops[i + 1].get("kernel", ""))):
@@ -240,13 +247,15 @@ def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc, want_tail=Fals
             assert frac < 0.02, (o["name"], frac)
         eng.write_tensor(t, c0, want)    # teacher forcing
     _dump(f"perop_bf16_{variant}", [(n, k, e) for n, k, e, _ in rows])
-    print(variant, "cfg", cfg, "ops checked", len(rows), "pwsp launches", npwsp, "fused dw->pw ops", nfused, "of them with the logit conv as third stage", ntail, "max ulp", max(r[2] for r in rows if r[1] != "f32"),
+    print(variant, "cfg", cfg, "ops checked", len(rows), "pwsp launches", npwsp, "cls_out launches", nclsout, "fused dw->pw ops", nfused, "of them with the logit conv as third stage", ntail, "max ulp", max(r[2] for r in rows if r[1] != "f32"),
           "max differing fraction", max(r[3] for r in rows))
     eng.close()
     load_library().yp_debug_force_conv_cfg(-1)
     assert len(rows) > 50
     assert nfused == 0 if not fuse else (nfused > 0 or shape != (2, 256, 384) or nc != 80)
     assert ntail > 0 if want_tail else ntail == 0
+    if fuse and cfg < 0 and variant == "s" and nc == 80 and not want_tail:
+        assert nclsout == 3, nclsout                 # one per level: the logit conv and the class-max keys in one launch
 
 
 def _final_report(res, ref, k):

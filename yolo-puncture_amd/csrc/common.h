@@ -88,6 +88,8 @@ struct Op {
     int fuse_tail = -1, tail_amax = -1;   // OP_CONV 1x1 without activation (fp32 logits): index of the dw->pw pointwise conv feeding it that can take it
                                   // on as a third stage, and of the OP_AMAX op behind it (or -1)
     bool fused6 = false;          // plan decision: dw -> pw -> this 1x1 (+ the class-max keys) run as conv_dwpw_kernel's TAIL form
+    int amax_post = -1;           // OP_CONV 1x1 that writes a level's fp32 class logits: index of the OP_AMAX op that reads them (graph pass)
+    bool fused8 = false;          // plan decision: logits and class-max keys come out of one cls_out_kernel launch; the OP_AMAX op is skipped
     int pw_pre = -1;              // OP_DWCONV (3x3 / 7x7, stride 1) / OP_POOL3: index of the 1x1 conv that produces its input and can run as the first stage of pwsp_kernel (graph pass)
     bool fused7 = false;          // plan decision: that 1x1 and this spatial op run as pwsp_kernel (one workgroup per image and channel slice); the 1x1 is skipped
     bool pw_store = false;        // fused7: the 1x1's own output has other readers and is written as well
@@ -390,6 +392,18 @@ const char* pwsp_kernel_name(const PwSpParams& p);
 constexpr int PWSP_CFG = 1000;                                                       // Op::cfg of a plain 1x1 conv that runs as pwsp_kernel<NS,0> (a tuner candidate)
 hipError_t launch_pwsp(const PwSpParams& p, hipStream_t st);
 hipError_t pwsp_read_clocks(unsigned long long* out32);
+
+// class logits + class-max keys in one kernel (cls_out.hip)
+struct ClsOutParams {
+    const void* x; int x_stride, x_coff; size_t x_bytes;      // bf16 [M][x_stride] view of K channels
+    int M, K, nc;
+    const void* w; int Kpad; size_t w_bytes; const float* bias;   // packed [nc^][K]
+    float* y; int y_stride, y_coff;                           // fp32 logits [M][y_stride]
+    unsigned* keys;                                           // [M]: bits of sigmoid(max_c y)
+};
+bool cls_out_valid(const ClsOutParams& p);
+const char* cls_out_kernel_name(const ClsOutParams& p);
+hipError_t launch_cls_out(const ClsOutParams& p, hipStream_t st);
 
 bool conv_dwpw_valid(const DwPwParams& p);
 const char* conv_dwpw_kernel_name(const DwPwParams& p);

@@ -664,6 +664,17 @@ static int finish_graph_passes(yp_engine& e) {
         c2.fuse_tail = (int)i - 1;
         if (i + 1 < e.ops.size() && e.ops[i + 1].kind == OP_AMAX && e.ops[i + 1].in.t == c2.out.t) c2.tail_amax = (int)i + 1;
     }
+    // ---- the 1x1 that writes a level's fp32 class logits + the class-max op that reads them: candidates for cls_out_kernel -----------------
+    for (size_t i = 0; i < e.ops.size(); ++i) {
+        const Op& m = e.ops[i];
+        if (m.kind != OP_AMAX) continue;
+        for (size_t j = 0; j < i; ++j) {
+            Op& c = e.ops[j];
+            if (c.kind == OP_CONV && c.k == 1 && c.s == 1 && c.act == ACT_NONE && c.res.t < 0 && c.fold_up < 0 && c.out.t == m.in.t && c.out.coff == 0 &&
+                c.out.C == e.tensors[c.out.t].C && e.tensors[c.out.t].f32 && m.in.coff == 0 && m.in.C == c.out.C)
+                c.amax_post = (int)i;
+        }
+    }
     // ---- 1x1 conv -> depthwise 3x3 / 7x7 (stride 1) or SPPF's pool chain on (a channel sub-range of) its output: candidates for pwsp_kernel,
     //      one workgroup per (image, channel slice) - the small-map layers (CIB, SPPF, the P5 class branch) --------------------------------
     for (size_t i = 0; i < e.ops.size(); ++i) {
@@ -700,6 +711,7 @@ static FrontParams front_params(const yp_engine& e, const Op& o, const uint8_t* 
 static C2fParams c2f_params(const yp_engine& e, const Op& o);
 static ScdParams scd_params(const yp_engine& e, const Op& o);
 static PwSpParams pwsp_params(const yp_engine& e, const Op& o);
+static ClsOutParams cls_out_params(const yp_engine& e, const Op& o);
 static bool views_overlap(const View& a, const View& b);
 static size_t tensor_elem_bytes(const yp_engine& e, const TensorDesc& t) { return (t.f32 || e.dtype == DT_F32) ? 4 : 2; }
 
@@ -805,7 +817,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
     e.pB = B; e.pH = H; e.pW = W; e.planned = true; e.allocated = false; e.warmed = false;
     for (auto& o : e.ops) o.cfg = -1;
     static const char* kn[] = {"stem_kernel", "", "dwconv_kernel", "pool5_kernel", "upsample2_kernel", "attention_kernel", "head_select_kernel", "", "sppf_pool3_kernel", "anchor_max_level_kernel"};
-    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; o.fused5 = false; o.fused6 = false; o.fused7 = false; o.pw_store = false; o.sparse_box = false; o.sparse_cf = false; }
+    for (auto& o : e.ops) { o.fused = false; o.skip = false; o.folded = false; o.fused2 = false; o.fused3 = false; o.fused4 = false; o.fused5 = false; o.fused6 = false; o.fused7 = false; o.fused8 = false; o.pw_store = false; o.sparse_box = false; o.sparse_cf = false; }
     static const bool no_fold = [] { const char* v = std::getenv("YOLOP_NO_FOLD"); return v && *v == '1'; }();   // A/B switch
     for (auto& o : e.ops) {
         if (o.kind != OP_CONV || o.fold_up < 0 || e.dtype != DT_BF16 || no_fold) continue;
@@ -966,6 +978,17 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
             d.kernel = pwsp_kernel_name(pwsp_params(e, d));
         }
     }
+    // class logits + class-max keys in one launch (cls_out_kernel): the OP_AMAX op is skipped
+    {
+        static const bool no_co = [] { const char* v = std::getenv("YOLOP_NO_CLSOUT"); return v && *v == '1'; }();   // A/B switch
+        for (auto& o : e.ops) {
+            if (o.kind != OP_CONV || o.amax_post < 0 || e.dtype != DT_BF16 || !e.fuse || no_co) continue;
+            if (o.skip || o.fused || o.fused2 || o.fused3 || o.fused4 || o.fused6 || o.folded || e.ops[o.amax_post].skip) continue;
+            if (!cls_out_valid(cls_out_params(e, o))) continue;
+            o.fused8 = true; e.ops[o.amax_post].skip = true;
+            o.kernel = cls_out_kernel_name(cls_out_params(e, o));
+        }
+    }
     // algorithmic work of the graph as it runs: an op whose work moved into a fused consumer reports nothing and launches
     // nothing; the consumer reports the FLOPs of all its stages and the bytes of what it reads and writes (the intermediates
     // never reach HBM), a conv with a folded upsample reads the low-resolution tensor instead of its upsampled copy
@@ -1002,6 +1025,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
                 o.bytes = vb(View{o.in.t, o.in.coff, 2 * m1.in.C}) + vb(o.out) + wb(m1) + wb(m2) + wb(o);
             }
             if (o.folded) { const Op& u = e.ops[o.fold_up]; o.bytes += vb(u.in) - vb(u.out); }
+            if (o.fused8) o.bytes += vb(e.ops[o.amax_post].out);
         }
         for (auto& o : e.ops) {
             if (o.kind != OP_HEAD) continue;
@@ -1188,6 +1212,19 @@ static ScdParams scd_params(const yp_engine& e, const Op& o) {
     return p;
 }
 
+static ClsOutParams cls_out_params(const yp_engine& e, const Op& o) {
+    ClsOutParams p{};
+    const WeightDesc& w = e.weights[o.widx];
+    const TensorDesc &ti = e.tensors[o.in.t], &to = e.tensors[o.out.t], &tk = e.tensors[e.ops[o.amax_post].out.t];
+    p.x = ti.ptr; p.x_stride = ti.C; p.x_coff = o.in.coff; p.x_bytes = ti.bytes;
+    p.M = e.pB * to.H * to.W; p.K = o.in.C; p.nc = o.out.C;
+    p.w = w.d_w; p.Kpad = w.Kpad; p.w_bytes = w.mat_bytes; p.bias = w.d_b;
+    p.y = (float*)to.ptr; p.y_stride = to.C; p.y_coff = o.out.coff;
+    p.keys = (unsigned*)tk.ptr;
+    if (w.cin_pad != o.in.C) p.K = 0;
+    return p;
+}
+
 // pwsp_kernel: `o` is the spatial op of a fused pair (o.fused7) or a plain 1x1 conv that runs in the same decomposition (cfg PWSP_CFG)
 static PwSpParams pwsp_params(const yp_engine& e, const Op& o) {
     PwSpParams p{};
@@ -1235,6 +1272,7 @@ static hipError_t run_op(yp_engine& e, const Op& o, const RunArgs& a, hipStream_
             if (o.fused3) return launch_frontend(front_params(e, o, a.in), st);
             if (o.fused4) return launch_c2f_fused(c2f_params(e, o), st);
             if (o.fused2) { const ConvParams q = conv_params(e, o); return launch_conv_halo_s2(q, o.cfg - 500, st); }
+            if (o.fused8) return launch_cls_out(cls_out_params(e, o), st);
             if (o.cfg == PWSP_CFG) return launch_pwsp(pwsp_params(e, o), st);
             if (conv_dma_forced_cfg() == PWSP_CFG && e.dtype == DT_BF16 && !o.folded) {          // test hook (yp_debug_force_conv_cfg): every 1x1 that admits it
                 const PwSpParams q = pwsp_params(e, o);
@@ -1411,7 +1449,7 @@ static int autotune(yp_engine& e) {
     };
     for (Op& o : e.ops) {
         if (o.kind != OP_CONV && o.kind != OP_CONVT) continue;
-        if (o.fused || o.fused2 || o.fused4 || o.fused6 || o.skip) continue;
+        if (o.fused || o.fused2 || o.fused4 || o.fused6 || o.fused8 || o.skip) continue;
         ConvParams p{};
         if (o.kind == OP_CONV) p = conv_params(e, o);
         else { p.Cin = o.in.C; p.Cout = o.out.C; p.ks = 1; p.Kpad = e.weights[o.widx].Kpad; p.M = e.pB * e.tensors[o.in.t].H * e.tensors[o.in.t].W;
@@ -1510,7 +1548,7 @@ static bool apply_tuning(yp_engine& e, const int* cfgs, int n) {
     if (n != (int)e.ops.size()) return false;
     for (size_t i = 0; i < e.ops.size(); ++i) {
         const Op& o = e.ops[i];
-        if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.fused6 || o.skip) continue;
+        if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.fused6 || o.fused8 || o.skip) continue;
         ConvParams p = tune_params(e, o);
         p.cfg = -1;
         if (cfgs[i] == PWSP_CFG) { if (o.kind != OP_CONV || o.folded || !pwsp_valid(pwsp_params(e, o))) return false; continue; }
@@ -1518,7 +1556,7 @@ static bool apply_tuning(yp_engine& e, const int* cfgs, int n) {
     }
     for (size_t i = 0; i < e.ops.size(); ++i) {
         Op& o = e.ops[i];
-        if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.fused6 || o.skip) continue;   // a fused op keeps its own symbol / id
+        if ((o.kind != OP_CONV && o.kind != OP_CONVT) || o.fused || o.fused2 || o.fused4 || o.fused6 || o.fused8 || o.skip) continue;   // a fused op keeps its own symbol / id
         o.cfg = cfgs[i];
         if (o.cfg == PWSP_CFG) { o.kernel = pwsp_kernel_name(pwsp_params(e, o)); continue; }
         ConvParams p = tune_params(e, o);
@@ -1621,6 +1659,7 @@ static void op_views(const yp_engine& e, const Op& o, std::vector<View>& rd, std
     if (o.res.t >= 0) rd.push_back(o.res);
     if (o.out.t >= 0) wr.push_back(o.out);
     if (o.fused7 && o.pw_store) wr.push_back(e.ops[o.pw_pre].out);
+    if (o.fused8) wr.push_back(e.ops[o.amax_post].out);
     if (o.fused6 && o.tail_amax >= 0) wr.push_back(e.ops[o.tail_amax].out);
     if (o.kind == OP_HEAD)
         for (int l = 0; l < 3; ++l) {
