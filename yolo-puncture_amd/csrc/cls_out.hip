@@ -23,14 +23,14 @@ __device__ __forceinline__ float co_sigmoid(float x) { return 1.0f / (1.0f + exp
 constexpr int CO_NW = 4;
 constexpr int CO_MAXNF = 8;             // up to 128 classes
 
-template <int TP>
+template <int TP, int NF>
 __global__ __launch_bounds__(CO_NW * 64) void cls_out_kernel(const ClsOutParams p, const int G) {
     constexpr int FM = TP / (16 * CO_NW);                          // pixel fragments per wave
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int RB = p.K * 2;                                        // bytes per row (a multiple of 128)
     const int CPR = RB >> 4;                                       // 16-byte chunks per row
-    const int nf = (p.nc + 15) >> 4;                               // channel fragments in use
+    constexpr int nf = NF;                                         // channel fragments (NF * 16 >= nc; rows beyond nc are zero weights)
     unsigned char* const Ws = smem;                                // [nf * 16][RB]
     unsigned char* const Xs = smem + (size_t)nf * 16 * RB;         // 2 x [TP][RB]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -57,36 +57,44 @@ __global__ __launch_bounds__(CO_NW * 64) void cls_out_kernel(const ClsOutParams 
     int tile = blockIdx.x;
     if (tile < ntiles) issue_rows(xrs, Xs, TP, (long)tile * TP, p.x_stride, p.x_coff, p.M);
 
-    float bias[CO_MAXNF][4];
+    float bias[NF][4];
 #pragma unroll
-    for (int a = 0; a < CO_MAXNF; ++a)
+    for (int a = 0; a < NF; ++a)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const int co = a * 16 + fc * 4 + r; bias[a][r] = (a < nf && co < p.nc) ? p.bias[co] : 0.f; }
+        for (int r = 0; r < 4; ++r) { const int co = a * 16 + fc * 4 + r; bias[a][r] = (co < p.nc) ? p.bias[co] : 0.f; }
+    // (known complete before the loop and passed through an empty asm statement: otherwise the compiler, which cannot count a loop
+    // iteration's vector-memory operations, waits `vmcnt(0)` in front of the accumulators' initialisation in every iteration - behind the
+    // next tile's loads, i.e. no prefetch; see conv_wres.hip)
+    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0xF << 8));
+#pragma unroll
+    for (int a = 0; a < NF; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(bias[a][r]));
 
     for (int it = 0; tile < ntiles; tile += G, ++it) {
         __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0xF << 8));     // vmcnt(0): this tile's rows (and the weights) have landed; the previous tile's stores are out
         __builtin_amdgcn_s_barrier();
         if (tile + G < ntiles) issue_rows(xrs, Xs + ((it & 1) ^ 1) * (size_t)TP * RB, TP, (long)(tile + G) * TP, p.x_stride, p.x_coff, p.M);
         const unsigned char* X = Xs + (it & 1) * (size_t)TP * RB;
-        f32x4 acc[CO_MAXNF][FM];
+        f32x4 acc[NF][FM];
 #pragma unroll
-        for (int a = 0; a < CO_MAXNF; ++a)
+        for (int a = 0; a < NF; ++a)
 #pragma unroll
             for (int f = 0; f < FM; ++f) acc[a][f] = f32x4{bias[a][0], bias[a][1], bias[a][2], bias[a][3]};
         const int nks = p.K >> 5;
+#pragma unroll 2
         for (int ks = 0; ks < nks; ++ks) {
             const int ch = ks * 4 + fc;
             const int pc = ch ^ (fr & 7);                                          // (row & 7 = fr & 7 for both operands' fragments)
-            bf16x8 xf[FM];
+            bf16x8 xf[FM], wf[NF];                                                 // (all reads of the substep, then its MFMAs: no branch in between)
 #pragma unroll
             for (int f = 0; f < FM; ++f) xf[f] = *(const bf16x8*)(X + (size_t)((wave * FM + f) * 16 + fr) * RB + pc * 16);
 #pragma unroll
-            for (int a = 0; a < CO_MAXNF; ++a) {
-                if (a >= nf) break;                                                // (uniform)
-                const bf16x8 wf = *(const bf16x8*)(Ws + (size_t)(a * 16 + fr) * RB + pc * 16);
+            for (int a = 0; a < NF; ++a) wf[a] = *(const bf16x8*)(Ws + (size_t)(a * 16 + fr) * RB + pc * 16);
 #pragma unroll
-                for (int f = 0; f < FM; ++f) acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf[f], acc[a][f], 0, 0, 0);
-            }
+            for (int a = 0; a < NF; ++a)
+#pragma unroll
+                for (int f = 0; f < FM; ++f) acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], xf[f], acc[a][f], 0, 0, 0);
         }
         // ---- logits out, class maximum -> key ---------------------------------------------------------------------------------
 #pragma unroll
@@ -95,8 +103,7 @@ __global__ __launch_bounds__(CO_NW * 64) void cls_out_kernel(const ClsOutParams 
             const bool ok = m < p.M;
             float mx = -INFINITY;
 #pragma unroll
-            for (int a = 0; a < CO_MAXNF; ++a) {
-                if (a >= nf) break;
+            for (int a = 0; a < NF; ++a) {
                 const int co = a * 16 + fc * 4;
                 if (co < p.nc) {                                                   // (nc % 4 == 0: a lane's four channels exist together)
                     mx = fmaxf(mx, fmaxf(fmaxf(acc[a][f][0], acc[a][f][1]), fmaxf(acc[a][f][2], acc[a][f][3])));
@@ -111,7 +118,8 @@ __global__ __launch_bounds__(CO_NW * 64) void cls_out_kernel(const ClsOutParams 
     __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0xF << 8));
 }
 
-static size_t cls_out_lds(const ClsOutParams& p, int TP) { return (size_t)((p.nc + 15) / 16 * 16) * p.K * 2 + (size_t)2 * TP * p.K * 2; }
+static int cls_out_nf(const ClsOutParams& p) { const int nf = (p.nc + 15) / 16; return nf <= 1 ? 1 : nf <= 5 ? 5 : CO_MAXNF; }   // instantiated fragment counts
+static size_t cls_out_lds(const ClsOutParams& p, int TP) { return (size_t)cls_out_nf(p) * 16 * p.K * 2 + (size_t)2 * TP * p.K * 2; }
 static int cls_out_tile(const ClsOutParams& p) { return cls_out_lds(p, 128) <= 78 * 1024 ? 128 : 64; }      // (small enough for two workgroups per CU, else the 64-pixel tile)
 
 bool cls_out_valid(const ClsOutParams& p) {
@@ -122,12 +130,16 @@ bool cls_out_valid(const ClsOutParams& p) {
     return cls_out_lds(p, cls_out_tile(p)) <= 150 * 1024;
 }
 
-const char* cls_out_kernel_name(const ClsOutParams& p) { return cls_out_tile(p) == 128 ? "cls_out_kernel<128>" : "cls_out_kernel<64>"; }
+const char* cls_out_kernel_name(const ClsOutParams& p) {
+    static const char* nm[2][3] = {{"cls_out_kernel<64,1>", "cls_out_kernel<64,5>", "cls_out_kernel<64,8>"}, {"cls_out_kernel<128,1>", "cls_out_kernel<128,5>", "cls_out_kernel<128,8>"}};
+    const int nf = cls_out_nf(p);
+    return nm[cls_out_tile(p) == 128][nf == 1 ? 0 : nf == 5 ? 1 : 2];
+}
 
-template <int TP>
+template <int TP, int NF>
 static hipError_t launch_cls_out_t(const ClsOutParams& p, hipStream_t st) {
     const size_t sh = cls_out_lds(p, TP);
-    auto kern = cls_out_kernel<TP>;
+    auto kern = cls_out_kernel<TP, NF>;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -144,7 +156,9 @@ static hipError_t launch_cls_out_t(const ClsOutParams& p, hipStream_t st) {
 
 hipError_t launch_cls_out(const ClsOutParams& p, hipStream_t st) {
     if (!cls_out_valid(p)) return hipErrorInvalidValue;
-    return cls_out_tile(p) == 128 ? launch_cls_out_t<128>(p, st) : launch_cls_out_t<64>(p, st);
+    const int nf = cls_out_nf(p);
+    if (cls_out_tile(p) == 128) return nf == 1 ? launch_cls_out_t<128, 1>(p, st) : nf == 5 ? launch_cls_out_t<128, 5>(p, st) : launch_cls_out_t<128, 8>(p, st);
+    return nf == 1 ? launch_cls_out_t<64, 1>(p, st) : nf == 5 ? launch_cls_out_t<64, 5>(p, st) : launch_cls_out_t<64, 8>(p, st);
 }
 
 }  // namespace yp

@@ -310,6 +310,12 @@ int conv_ks_num_cfgs();
 bool conv_ks_cfg_valid(const ConvParams& p, int c);
 const char* conv_ks_kernel_name(int c);
 hipError_t launch_conv_ks(const ConvParams& p, int c, hipStream_t st);
+// weights-resident streaming 1x1 kernel (conv_wres.hip); ids offset by 1100
+int conv_wres_num_cfgs();
+bool conv_wres_cfg_valid(const ConvParams& p, int c);
+const char* conv_wres_kernel_name(int c);
+hipError_t launch_conv_wres(const ConvParams& p, int c, hipStream_t st);
+
 // pixels-direct 1x1 kernel (conv_pxd.hip); ids offset by 800
 int conv_pxd_num_cfgs();
 bool conv_pxd_cfg_valid(const ConvParams& p, int c);

@@ -1484,6 +1484,8 @@ static int autotune(yp_engine& e) {
             for (int c = 0; !no_px && c < conv_pxd_num_cfgs(); ++c) if (conv_pxd_cfg_valid(p, c)) cands.push_back(800 + c);
             static const bool no_ks = [] { const char* v = std::getenv("YOLOP_NO_KS"); return v && *v == '1'; }();     // A/B switch
             for (int c = 0; !no_ks && c < conv_ks_num_cfgs(); ++c) if (conv_ks_cfg_valid(p, c)) cands.push_back(900 + c);
+            static const bool no_wres = [] { const char* v = std::getenv("YOLOP_NO_WRES"); return v && *v == '1'; }();   // A/B switch
+            for (int c = 0; !no_wres && c < conv_wres_num_cfgs(); ++c) if (conv_wres_cfg_valid(p, c)) cands.push_back(1100 + c);
             static const bool no_ps = [] { const char* v = std::getenv("YOLOP_NO_PWSP"); return v && *v == '1'; }();     // A/B switch
             if (!no_ps && !o.folded && p.x2_C == 0 && pwsp_valid(pwsp_params(e, o))) cands.push_back(PWSP_CFG);
             for (int cc : cands) {
@@ -1525,7 +1527,7 @@ static int autotune(yp_engine& e) {
 
 // Optional on-disk cache of the autotuner's choices (env YOLOP_TUNE_CACHE=<path prefix>): one file per
 // (variant, task, dtype, B, H, W), lines "<op name> <cfg>". Lets a profiled run skip the tuning launches.
-static const int TUNE_TABLE_VERSION = 4;
+static const int TUNE_TABLE_VERSION = 5;
 static std::string tune_cache_path(const yp_engine& e) {
     const char* pre = std::getenv("YOLOP_TUNE_CACHE");
     if (!pre || !*pre) return "";

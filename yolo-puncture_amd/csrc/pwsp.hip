@@ -110,11 +110,15 @@ __global__ __launch_bounds__(PS_NT) void pwsp_kernel(const PwSpParams p) {
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     // this lane's role in a pixel piece: row lane >> 3 of the piece's 8 rows, 16-byte position lane & 7, which holds source chunk
     // (lane & 7) ^ ((row >> 1) & 7) - the swizzle the fragment reads undo
+    // (K % 64 == 32 - the 288- / 96-channel layers of v10-M / -N: the last k-step's upper four chunks lie behind the row's K channels, in the
+    // next pixel / the next weight row. Both operands read zeros there: `kc` = the lane's chunk, compared against K per step.)
     unsigned pa_off[2], pb_off[2];
+    int p_kc[2], w_kc;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int row = (wave * 2 + j) * 8 + (lane >> 3);                     // row within the slot = pixel (A) / pixel - 256 (B)
         const int c = (lane & 7) ^ ((row >> 1) & 7);
+        p_kc[j] = c * 8;
         pa_off[j] = (row < HW && row < 256) ? (unsigned)((b * HW + row) * p.x_stride + p.x_coff + c * 8) * 2u : OOB;
         pb_off[j] = (row + 256 < HW) ? (unsigned)((b * HW + row + 256) * p.x_stride + p.x_coff + c * 8) * 2u : OOB;
     }
@@ -123,6 +127,7 @@ __global__ __launch_bounds__(PS_NT) void pwsp_kernel(const PwSpParams p) {
         const int s_ = wave * 64 + lane;
         const int row = s_ >> 3, pc = s_ & 7;
         const int c = pc ^ ((row >> 1) & 7);
+        w_kc = c * 8;
         wconst = (wave < W_INSTR) ? (unsigned)(((n0 + row) * p.Kpad1 + c * 8) * 2) : OOB;
     }
     auto kbyte = [&](int kt) { return (unsigned)(kt * BK) * 2u; };
@@ -130,11 +135,11 @@ __global__ __launch_bounds__(PS_NT) void pwsp_kernel(const PwSpParams p) {
         const bool live = kt < nk;
         const unsigned kb = kbyte(kt);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_void*)((wave < W_INSTR) ? wring + (kt % NSLOT) * SLOT + wave * 1024 : dump), 16,
-                                                 (live && wconst != OOB) ? wconst + kb : OOB, 0, 0, 0);
+                                                 (live && wconst != OOB && kt * BK + w_kc < p.K) ? wconst + kb : OOB, 0, 0, 0);
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(pxa + (kt & 1) * PXS + (wave * 2 + j) * 1024), 16,
-                                                     (live && pa_off[j] != OOB && !(p.dbg & 2)) ? pa_off[j] + kb : OOB, 0, 0, 0);
+                                                     (live && pa_off[j] != OOB && kt * BK + p_kc[j] < p.K && !(p.dbg & 2)) ? pa_off[j] + kb : OOB, 0, 0, 0);
     };
     auto issue_B = [&](int kt) {
         const bool live = kt < nk;
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(PS_NT) void pwsp_kernel(const PwSpParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(pxb + (kt & 1) * PXS + (wave * 2 + j) * 1024), 16,
-                                                     (live && pb_off[j] != OOB && !(p.dbg & 2)) ? pb_off[j] + kb : OOB, 0, 0, 0);
+                                                     (live && pb_off[j] != OOB && kt * BK + p_kc[j] < p.K && !(p.dbg & 2)) ? pb_off[j] + kb : OOB, 0, 0, 0);
     };
 
     f32x4 acc[FN][PS_MF];
