@@ -88,9 +88,9 @@ def _ulps_bf16(got, want):
                           ("s", False, (2, 256, 384), -1, True), ("s", False, (2, 256, 384), -1, False),
                           ("s", False, (1, 480, 608), -1, True), ("m", False, (2, 128, 160), -1, True)] +   # (m: 288- / 576-channel rows, K % 64 == 32)      # 60x76 at P3: partial tiles of the fused SCDown (4x8) and C2f-tail (8x16) kernels
 
-                         [("s", True, (3, 96, 160), c, True) for c in list(range(14)) + [100, 101, 102, 103, 200, 201, 202, 203, 204] + list(range(300, 341)) + list(range(400, 409)) + list(range(500, 505)) + [600, 601, 602] + list(range(700, 713)) + list(range(800, 808)) + list(range(900, 904)) + [1000, 1100, 1101, 1102]] +
+                         [("s", True, (3, 96, 160), c, True) for c in list(range(14)) + [100, 101, 102, 103, 200, 201, 202, 203, 204] + list(range(300, 341)) + list(range(400, 409)) + list(range(500, 505)) + [600, 601, 602] + list(range(700, 713)) + list(range(800, 808)) + list(range(900, 904)) + [1000, 1100, 1101, 1102, 1200, 1201]] +
                          [("s", False, (1, 256, 256), c, True) for c in range(500, 505)] +    # stride-2 halo family: model.1 / .3 / .17 all valid here
-                         [(v, False, (2, 128, 160), c, True) for v in ("x", "m") for c in (1100, 1101, 1102)] +   # weights-resident 1x1: 80 / 320-, 48 / 192-channel rows, 3-5 channel blocks
+                         [(v, False, (2, 128, 160), c, True) for v in ("x", "m") for c in (1100, 1101, 1102, 1200, 1201)] +   # weights-resident 1x1: 80 / 320-, 48 / 192-channel rows, 3-5 channel blocks
                          [("x", False, (1, 64, 64), c, True) for c in (801, 803, 807)])       # pixels-direct 1x1 with Cin % 64 == 32 (80 / 160 / 480-channel layers of v10-X)
 def test_per_op_bf16_teacher_forced(variant, seg, shape, cfg, fuse, monkeypatch):
     _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, 80)
@@ -139,7 +139,7 @@ def _per_op_bf16(variant, seg, shape, cfg, fuse, monkeypatch, nc, want_tail=Fals
         k7 = [str(o.get("kernel", "")) for o in ops if o["name"].endswith("cv1.2")]
         assert k7 and all(k.startswith(("dwconv_mfma", "pwsp_kernel") if fuse else "dwconv_mfma") for k in k7), k7
     if cfg >= 1100:
-        assert variant != "s" or any(str(o.get("kernel", "")).startswith("conv_wres_kernel") for o in ops), "no op took the forced weights-resident configuration"
+        assert variant != "s" or any(str(o.get("kernel", "")).startswith("conv_wres_kernel" if cfg < 1200 else "conv_wrs_kernel") for o in ops), "no op took the forced weights-resident configuration"
     rows = []
     from yolo_puncture_amd.weights import fold_state
     folded = fold_state(st)

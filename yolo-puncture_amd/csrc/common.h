@@ -316,6 +316,12 @@ bool conv_wres_cfg_valid(const ConvParams& p, int c);
 const char* conv_wres_kernel_name(int c);
 hipError_t launch_conv_wres(const ConvParams& p, int c, hipStream_t st);
 
+// weights-in-registers streaming 1x1 kernel (conv_wrs.hip); ids offset by 1200
+int conv_wrs_num_cfgs();
+bool conv_wrs_cfg_valid(const ConvParams& p, int c);
+const char* conv_wrs_kernel_name(int c);
+hipError_t launch_conv_wrs(const ConvParams& p, int c, hipStream_t st);
+
 // pixels-direct 1x1 kernel (conv_pxd.hip); ids offset by 800
 int conv_pxd_num_cfgs();
 bool conv_pxd_cfg_valid(const ConvParams& p, int c);

@@ -254,7 +254,7 @@ static int conv_tile_choice(const ConvParams& p) {
 static int halo_choice(const ConvParams& p, int dtype) {
     if (dtype != DT_BF16) return -1;
     if (p.x2_C > 0) {        // folded upsample: only the persistent LDS-DMA families implement the two-source gather
-        auto ok = [&](int c) { return c >= 1100 ? conv_wres_cfg_valid(p, c - 1100) : c >= 900 ? false : c >= 800 ? conv_pxd_cfg_valid(p, c - 800) : (c >= 400 && c < 500 ? conv_dma_lc_cfg_valid(p, c - 400) : (c >= 300 && c < 400 && conv_dma_p_cfg_valid(p, c - 300))); };
+        auto ok = [&](int c) { return c >= 1200 ? conv_wrs_cfg_valid(p, c - 1200) : c >= 1100 ? conv_wres_cfg_valid(p, c - 1100) : c >= 900 ? false : c >= 800 ? conv_pxd_cfg_valid(p, c - 800) : (c >= 400 && c < 500 ? conv_dma_lc_cfg_valid(p, c - 400) : (c >= 300 && c < 400 && conv_dma_p_cfg_valid(p, c - 300))); };
         const int f = conv_dma_forced_cfg();
         if (ok(f)) return f;
         if (ok(p.cfg)) return p.cfg;
@@ -263,6 +263,7 @@ static int halo_choice(const ConvParams& p, int dtype) {
         return -2;
     }
     auto valid = [&](int c) {
+        if (c >= 1200) return conv_wrs_cfg_valid(p, c - 1200);
         if (c >= 1100) return conv_wres_cfg_valid(p, c - 1100);
         if (c >= 1000) return false;                                 // (1000 = pwsp_kernel: the engine launches it itself)
         if (c >= 900) return conv_ks_cfg_valid(p, c - 900);
@@ -284,11 +285,12 @@ static int halo_choice(const ConvParams& p, int dtype) {
 }
 
 // Is tile configuration id `cfg` (the autotuner's numbering: < 100 conv_dma, 100+ conv_halo, 200+ conv_halo_p, 300+ conv_dma_p, 400+ conv_dma_lc,
-// 500+ conv_halo_s2, 600+ conv_tile1, 700+ conv_wreg, 800+ conv_pxd, 900+ conv_ks, 1100+ conv_wres; -1 = heuristic) one this build can launch for p? Used for
+// 500+ conv_halo_s2, 600+ conv_tile1, 700+ conv_wreg, 800+ conv_pxd, 900+ conv_ks, 1100+ conv_wres, 1200+ conv_wrs; -1 = heuristic) one this build can launch for p? Used for
 // configurations that come from outside the tuner (tune cache files, yp_tuning_import).
 bool conv_cfg_usable(const ConvParams& p, int dtype, int cfg) {
     if (cfg == -1) return true;
     if (dtype != DT_BF16 || cfg < -1) return false;
+    if (cfg >= 1200) return cfg - 1200 < conv_wrs_num_cfgs() && conv_wrs_cfg_valid(p, cfg - 1200);
     if (cfg >= 1100) return cfg - 1100 < conv_wres_num_cfgs() && conv_wres_cfg_valid(p, cfg - 1100);
     if (cfg >= 1000) return false;
     if (cfg >= 900) return cfg - 900 < conv_ks_num_cfgs() && p.x2_C == 0 && conv_ks_cfg_valid(p, cfg - 900);
@@ -305,6 +307,7 @@ bool conv_cfg_usable(const ConvParams& p, int dtype, int cfg) {
 
 const char* conv_kernel_name(const ConvParams& p, int dtype) {
     const int h = halo_choice(p, dtype);
+    if (h >= 1200) return conv_wrs_kernel_name(h - 1200);
     if (h >= 1100) return conv_wres_kernel_name(h - 1100);
     if (h >= 900) return conv_ks_kernel_name(h - 900);
     if (h >= 800) return conv_pxd_kernel_name(h - 800);
@@ -352,6 +355,7 @@ hipError_t launch_conv_igemm(const ConvParams& p, int dtype, hipStream_t st) {
 hipError_t launch_conv(const ConvParams& p, int dtype, hipStream_t st) {
     const int h = halo_choice(p, dtype);
     if (p.x2_C > 0 && h < 300) return hipErrorInvalidValue;      // (the plan folds an upsample only when such a configuration exists)
+    if (h >= 1200) return launch_conv_wrs(p, h - 1200, st);
     if (h >= 1100) return launch_conv_wres(p, h - 1100, st);
     if (h >= 900) return launch_conv_ks(p, h - 900, st);
     if (h >= 800) return launch_conv_pxd(p, h - 800, st);
