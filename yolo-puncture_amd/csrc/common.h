@@ -386,6 +386,8 @@ struct DwPwParams {                              // fused depthwise 3x3 s1 -> po
     float* y3; int y3_stride, y3_coff; size_t y3_bytes;
     unsigned* keys;
 };
+bool dwpw_stream_valid(const DwPwParams& p);                    // the streaming form for 128-channel inputs (conv_dwpw_stream.hip)
+hipError_t launch_dwpw_stream(const DwPwParams& p, hipStream_t st);
 // pointwise 1x1 -> per-channel spatial operator, one workgroup per (image, channel slice) (pwsp.hip): the small-map layers
 struct PwSpParams {
     const void* x; int x_stride, x_coff; size_t x_bytes; int B, H, W, K;           // input view [B,H,W,K]

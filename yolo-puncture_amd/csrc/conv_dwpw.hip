@@ -447,6 +447,7 @@ static int dwpw_bn(const DwPwParams& p) {          // widest output-channel bloc
 }
 
 bool conv_dwpw_valid(const DwPwParams& p) {
+    if (dwpw_stream_valid(p)) return true;
     if ((p.C % 32) != 0 || p.Kpad != p.C || (p.Cout & 3) || (p.y_stride & 3) || (p.y_coff & 3)) return false;
     if (p.x_bytes >= (1ull << 31) || p.y_bytes >= (1ull << 31) || p.wpw_bytes >= (1ull << 31)) return false;
     if ((long)((p.H + 7) / 8 * 8) * ((p.W + 15) / 16 * 16) * 2 > (long)p.H * p.W * 3) return false;
@@ -465,6 +466,7 @@ bool conv_dwpw_valid(const DwPwParams& p) {
 }
 
 const char* conv_dwpw_kernel_name(const DwPwParams& p) {
+    if (dwpw_stream_valid(p)) return "conv_dwpw_stream_kernel";
     const int bn = dwpw_bn(p);
     if (dwpw_tail(p)) return bn == 128 ? "conv_dwpw_kernel<8,128,tail,8>" : "conv_dwpw_kernel<8,64,tail,8>";
     if (p.out_f32) return bn == 128 ? "conv_dwpw_kernel<8,128,true,8>" : "conv_dwpw_kernel<8,64,true,8>";
@@ -516,6 +518,7 @@ static hipError_t launch_dwpw_t(const DwPwParams& p, hipStream_t st) {
 }
 
 hipError_t launch_conv_dwpw(const DwPwParams& p, hipStream_t st) {
+    if (dwpw_stream_valid(p)) return launch_dwpw_stream(p, st);
     const int bn = dwpw_bn(p);
     if (dwpw_tail(p)) return bn == 128 ? launch_dwpw_t<128, false, true>(p, st) : launch_dwpw_t<64, false, true>(p, st);
     if (bn == 128) return p.out_f32 ? launch_dwpw_t<128, true>(p, st) : launch_dwpw_t<128, false>(p, st);
