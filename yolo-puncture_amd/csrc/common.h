@@ -185,6 +185,10 @@ struct ScdParams {
     unsigned long long* clk;                                                          // debug (YOLOP_SCD_CLOCKS=1), else null
 };
 bool scdown_fused_valid(const ScdParams& p);
+const char* scdown_fused_kernel_name(const ScdParams& p);
+bool scdown_stream_valid(const ScdParams& p);                     // the streaming form for 256 output channels (scdown_stream.hip)
+const char* scdown_stream_kernel_name(const ScdParams& p);
+hipError_t launch_scdown_stream(const ScdParams& p, hipStream_t st);
 hipError_t launch_scdown_fused(const ScdParams& p, hipStream_t st);
 hipError_t launch_c2f_fused(const C2fParams& p, hipStream_t st);
 

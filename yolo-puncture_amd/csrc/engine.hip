@@ -885,7 +885,7 @@ static int make_plan(yp_engine& e, int B, int H, int W) {
         } else if (o.kind == OP_DWCONV) {
             static const bool no_scd = [] { const char* v = std::getenv("YOLOP_NO_SCD"); return v && *v == '1'; }();   // A/B switch
             if (o.scd_pre >= 0 && e.dtype == DT_BF16 && e.fuse && !no_scd && scdown_fused_valid(scd_params(e, o))) {
-                o.fused5 = true; e.ops[o.scd_pre].skip = true; o.kernel = "scdown_fused_kernel";
+                o.fused5 = true; e.ops[o.scd_pre].skip = true; o.kernel = scdown_fused_kernel_name(scd_params(e, o));
                 continue;
             }
             const char* t = e.dtype == DT_BF16 ? "bf16" : "f32";

@@ -220,7 +220,10 @@ __global__ __launch_bounds__(SD_NW * 64) void scdown_fused_kernel(const ScdParam
         for (int i = 0; i < 4; ++i) p.clk[((size_t)blockIdx.x * SD_NW + wave) * 4 + i] = clk[i];
 }
 
+const char* scdown_fused_kernel_name(const ScdParams& p) { return scdown_stream_valid(p) ? scdown_stream_kernel_name(p) : "scdown_fused_kernel"; }
+
 bool scdown_fused_valid(const ScdParams& p) {
+    if (scdown_stream_valid(p)) return true;
     if (p.K != 128 || p.Kpad1 != 128 || (p.C & 63) || p.C > 256 || p.C < 64) return false;
     if ((p.x_stride & 7) || (p.x_coff & 7) || (p.y_stride & 3) || (p.y_coff & 3)) return false;
     if (p.x_bytes >= (1ull << 31) || p.y_bytes >= (1ull << 31)) return false;
@@ -232,6 +235,7 @@ bool scdown_fused_valid(const ScdParams& p) {
 }
 
 hipError_t launch_scdown_fused(const ScdParams& p, hipStream_t st) {
+    if (scdown_stream_valid(p)) return launch_scdown_stream(p, st);
     const int tiles_h = (p.Ho + SD_TH - 1) / SD_TH, tiles_w = (p.Wo + SD_TW - 1) / SD_TW;
     const int num_tiles = p.B * tiles_h * tiles_w;
     int G = 256;
