@@ -211,7 +211,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_dwpw_stream_kernel(const DwPw
 bool dwpw_stream_valid(const DwPwParams& p) {
     static const bool off = [] { const char* v = std::getenv("YOLOP_NO_DWPW_STREAM"); return v && *v == '1'; }();   // A/B switch
     if (off || p.w3 || p.out_f32 || p.clk) return false;
-    if (p.C != DS_C || p.Kpad != DS_C || p.Cout > 128 || p.Cout < 68 || (p.Cout & 3)) return false;
+    if (p.C != DS_C || p.Kpad != DS_C || p.Cout != 128) return false;      // (the class branch of the 128-wide heads: v10-S; other widths keep the chunked kernel)
     if ((p.x_stride & 7) || (p.x_coff & 7) || (p.y_stride & 3) || (p.y_coff & 3)) return false;
     if (p.x_bytes >= (1ull << 31) || p.y_bytes >= (1ull << 31) || p.wpw_bytes >= (1ull << 31)) return false;
     if (p.act_dw != ACT_SILU && p.act_dw != ACT_NONE) return false;
