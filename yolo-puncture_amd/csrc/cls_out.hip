@@ -24,7 +24,7 @@ constexpr int CO_NW = 4;
 constexpr int CO_MAXNF = 8;             // up to 128 classes
 
 template <int TP, int NF>
-__global__ __launch_bounds__(CO_NW * 64) void cls_out_kernel(const ClsOutParams p, const int G) {
+__global__ __launch_bounds__(CO_NW * 64) void cls_out_kernel(const ClsOutParams p, const int G, const int TPe) {
     constexpr int FM = TP / (16 * CO_NW);                          // pixel fragments per wave
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(CO_NW * 64) void cls_out_kernel(const ClsOutParams 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fc = lane >> 4;
-    const int ntiles = (p.M + TP - 1) / TP;
+    const int ntiles = (p.M + TPe - 1) / TPe;                     // TPe <= TP rows of a tile in use: equal pixels per workgroup (conv_wres.hip)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
 
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(CO_NW * 64) void cls_out_kernel(const ClsOutParams 
     };
     issue_rows(wrs, Ws, nf * 16, 0, p.Kpad, 0, (long)(p.nc + 127) / 128 * 128);      // (rows beyond nc are the packed matrix's zero padding)
     int tile = blockIdx.x;
-    if (tile < ntiles) issue_rows(xrs, Xs, TP, (long)tile * TP, p.x_stride, p.x_coff, p.M);
+    if (tile < ntiles) issue_rows(xrs, Xs, TPe, (long)tile * TPe, p.x_stride, p.x_coff, p.M);
 
     float bias[NF][4];
 #pragma unroll
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(CO_NW * 64) void cls_out_kernel(const ClsOutParams 
     for (int it = 0; tile < ntiles; tile += G, ++it) {
         __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0xF << 8));     // vmcnt(0): this tile's rows (and the weights) have landed; the previous tile's stores are out
         __builtin_amdgcn_s_barrier();
-        if (tile + G < ntiles) issue_rows(xrs, Xs + ((it & 1) ^ 1) * (size_t)TP * RB, TP, (long)(tile + G) * TP, p.x_stride, p.x_coff, p.M);
+        if (tile + G < ntiles) issue_rows(xrs, Xs + ((it & 1) ^ 1) * (size_t)TP * RB, TPe, (long)(tile + G) * TPe, p.x_stride, p.x_coff, p.M);
         const unsigned char* X = Xs + (it & 1) * (size_t)TP * RB;
         f32x4 acc[NF][FM];
 #pragma unroll
@@ -99,8 +99,9 @@ __global__ __launch_bounds__(CO_NW * 64) void cls_out_kernel(const ClsOutParams 
         // ---- logits out, class maximum -> key ---------------------------------------------------------------------------------
 #pragma unroll
         for (int f = 0; f < FM; ++f) {
-            const long m = (long)tile * TP + (wave * FM + f) * 16 + fr;
-            const bool ok = m < p.M;
+            const int ri = (wave * FM + f) * 16 + fr;
+            const long m = (long)tile * TPe + ri;
+            const bool ok = ri < TPe && m < p.M;
             float mx = -INFINITY;
 #pragma unroll
             for (int a = 0; a < NF; ++a) {
@@ -150,7 +151,9 @@ static hipError_t launch_cls_out_t(const ClsOutParams& p, hipStream_t st) {
     // (an HBM-bound kernel: as many workgroups as fit - two per CU when the tiles are small - each walking every G-th tile)
     int G = sh <= 78 * 1024 ? 512 : 256;
     if (G > ntiles) G = ntiles;
-    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(CO_NW * 64), sh, st, p, G);
+    const int rounds = (int)((p.M + (long)G * TP - 1) / ((long)G * TP));
+    const int TPe = tile_balance_enabled(4) ? (int)((p.M + (long)G * rounds - 1) / ((long)G * rounds)) : TP;       // equal pixels per workgroup
+    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(CO_NW * 64), sh, st, p, G, TPe);
     return hipGetLastError();
 }
 

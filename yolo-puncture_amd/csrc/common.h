@@ -295,6 +295,7 @@ void conv_dma_force_cfg(int cfg);
 int conv_dma_forced_cfg();
 void conv_set_debug_ablation(int v);
 int conv_debug_ablation();
+bool tile_balance_enabled(int family);  // tiles sized to whole rounds of workgroups? family 1 = conv_pxd, 2 = conv_wres, 4 = cls_out; YOLOP_BALANCE=<mask> (A/B switch)
 // halo-tiled 3x3 s1 kernel (conv_halo.hip); configuration ids are offset by 100 in ConvParams::cfg
 int conv_halo_num_cfgs();
 bool conv_halo_cfg_valid(const ConvParams& p, int c);

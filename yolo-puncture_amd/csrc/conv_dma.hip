@@ -13,6 +13,7 @@
 // blocks per SURVEY.md Appendix A.2 [U]. Used when Cin % 32 == 0 in bf16 mode; everything else (fp32 mode,
 // Cin = 16 / 80) runs conv_igemm.hip.
 #include "common.h"
+#include <cstdlib>
 
 namespace yp {
 
@@ -293,6 +294,7 @@ int conv_dma_forced_cfg() { return g_force_cfg; }
 static int g_dbg_ablate = 0;
 void conv_set_debug_ablation(int v) { g_dbg_ablate = v; }
 int conv_debug_ablation() { return g_dbg_ablate; }
+bool tile_balance_enabled(int family) { static const int mask = [] { const char* v = std::getenv("YOLOP_BALANCE"); return v ? atoi(v) : 6; }(); return (mask & family) != 0; }
 static int dma_choice(const ConvParams& p) {
     if (conv_dma_cfg_valid(p, g_force_cfg)) return g_force_cfg;
     return conv_dma_cfg_valid(p, p.cfg) ? p.cfg : dma_heuristic(p);

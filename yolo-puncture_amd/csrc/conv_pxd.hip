@@ -26,7 +26,7 @@ template <int N> __device__ __forceinline__ void px_wait_vmc() {
 }
 
 template <int PXW, int FN, int WGM, int WGN, bool HAS_RES, bool OUT_F32>
-__global__ __launch_bounds__(WGM * WGN * 64) void conv_pxd_kernel(const ConvParams p, const int mtiles) {
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_pxd_kernel(const ConvParams p, const int mtiles, const int BMe) {
     constexpr int NW = WGM * WGN;
     constexpr int BM = WGM * PXW * 16, BN = WGN * FN * 16;
     constexpr int BK = 64, NS = 3;
@@ -51,7 +51,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_pxd_kernel(const ConvPara
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
     }
     const int mt = bid % mtiles, nt = bid / mtiles;
-    const int m0 = mt * BM, n0 = nt * BN;
+    // BMe <= BM rows of a tile are in use: the host sizes the tiles so that the launch is whole rounds of workgroups (a 40x40 map at batch 32
+    // is 200 tiles of 256 pixels on 256 CUs; 256 tiles of 200 pixels keep every CU busy and finish a fifth earlier)
+    const int m0 = mt * BMe, n0 = nt * BN;
     const int nk = (p.Kpad + BK - 1) / BK;            // Kpad % 32 == 0: a trailing half step reads zero pixels (its weight bytes are then irrelevant)
 
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.w_bytes, 0x00020000);
@@ -61,9 +63,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_pxd_kernel(const ConvPara
     unsigned xoff[PXW], xoff2[PXW];
 #pragma unroll
     for (int f = 0; f < PXW; ++f) {
-        const int m = m0 + (wm * PXW + f) * 16 + fr;
+        const int ri = (wm * PXW + f) * 16 + fr;
+        const int m = m0 + ri;
         xoff[f] = OOB; xoff2[f] = OOB;
-        if (m < p.M) {
+        if (ri < BMe && m < p.M) {
             xoff[f] = (unsigned)(m * p.x_stride + p.x_coff) * 2u + (unsigned)fc * 16u;
             if (p.x2_C > 0) {
                 const int HoWo = p.Ho * p.Wo;
@@ -195,8 +198,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_pxd_kernel(const ConvPara
     // ---- epilogue --------------------------------------------------------------------------------------------------------------
 #pragma unroll
     for (int f = 0; f < PXW; ++f) {
-        const int m = m0 + (wm * PXW + f) * 16 + fr;
-        const bool pix_ok = m < p.M;
+        const int ri = (wm * PXW + f) * 16 + fr;
+        const int m = m0 + ri;
+        const bool pix_ok = ri < BMe && m < p.M;
 #pragma unroll
         for (int a = 0; a < FN; ++a) {
             const int co = n0 + wn * (FN * 16) + a * 16 + fc * 4;
@@ -258,7 +262,18 @@ const char* conv_pxd_kernel_name(int c) { return kPxd[c].name; }
 template <int PXW, int FN, int WGM, int WGN, bool HAS_RES, bool OUT_F32>
 static hipError_t launch_pxd_var(const ConvParams& p, hipStream_t st) {
     constexpr int BM = WGM * PXW * 16, BN = WGN * FN * 16;
-    const int mtiles = (p.M + BM - 1) / BM, ntiles = (p.Cout + BN - 1) / BN;
+    const int ntiles = (p.Cout + BN - 1) / BN;
+    // whole rounds of 256 workgroups: the rounds the full tiles need, then the tile height that fills exactly those rounds
+    int BMe = BM;
+    if (tile_balance_enabled(1)) {
+        const long full = (long)((p.M + BM - 1) / BM) * ntiles;
+        const long rounds = (full + 255) / 256;
+        const long lanes = rounds * 256 / ntiles;                  // pixel tiles that fit those rounds
+        if (lanes > 0) BMe = (int)((p.M + lanes - 1) / lanes);
+        if (BMe > BM) BMe = BM;
+        if (BMe < 16) BMe = 16;
+    }
+    const int mtiles = (p.M + BMe - 1) / BMe;
     const size_t sh = (size_t)3 * (BN * 8 / 64) * 1024 + 1024;
     auto kern = conv_pxd_kernel<PXW, FN, WGM, WGN, HAS_RES, OUT_F32>;
     static bool attr = false;
@@ -267,7 +282,7 @@ static hipError_t launch_pxd_var(const ConvParams& p, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr = true;
     }
-    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(WGM * WGN * 64), sh, st, p, mtiles);
+    hipLaunchKernelGGL(kern, dim3(mtiles * ntiles), dim3(WGM * WGN * 64), sh, st, p, mtiles, BMe);
     return hipGetLastError();
 }
 

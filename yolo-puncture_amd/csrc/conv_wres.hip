@@ -42,7 +42,7 @@ template <int N, int FM, int NFW> __device__ __forceinline__ void wr_wait_lgkm(b
 }
 
 template <int TP, int WGN, bool HAS_RES>
-__global__ __launch_bounds__(WR_NW * 64) void conv_wres_kernel(const ConvParams p, const int NB, const int nblk, const int G) {
+__global__ __launch_bounds__(WR_NW * 64) void conv_wres_kernel(const ConvParams p, const int NB, const int nblk, const int G, const int TPe) {
     constexpr int WGM = WR_NW / WGN;
     constexpr int FM = TP / (16 * WGM);                            // pixel fragments per wave
     constexpr int NFW = WR_MAXNF / WGN;                            // channel fragments per wave at most
@@ -63,7 +63,9 @@ __global__ __launch_bounds__(WR_NW * 64) void conv_wres_kernel(const ConvParams 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave % WGM, wn = wave / WGM;
     const int fr = lane & 15, fc = lane >> 4;
-    const int ntiles = (p.M + TP - 1) / TP;
+    // TPe <= TP rows of a tile are in use: the host sizes the tiles so that every tile lane gets the same number of pixels (a 40x40 map in
+    // 64-pixel tiles is 3.1 tiles per lane = four rounds of which the last is mostly idle; four rounds of 50 pixels are not)
+    const int ntiles = (p.M + TPe - 1) / TPe;
     const int HoWo = p.Ho * p.Wo;
 
     // workgroup -> (channel block, tile lane): the blocks of one tile lane are neighbours on one XCD (G % (8 * nblk) == 0)
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(WR_NW * 64) void conv_wres_kernel(const ConvParams 
 
     // rows are written 16 bytes per lane, whole rows per piece, swizzled as above
     auto issue_tile = [&](int tile, unsigned char* dst) {
-        const long row0 = (long)tile * TP;
+        const long row0 = (long)tile * TPe;
         if (KA > 0) {                                              // segment A: channels [0, KA) of pixel (b, ho, wo) live at (b, ho >> 1, wo >> 1) of x2
             const int cpr = RBA >> 4, pieces = (TP * cpr) >> 6;
             for (int ii = wave; ii < pieces; ii += WR_NW) {
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(WR_NW * 64) void conv_wres_kernel(const ConvParams 
                 const int c = pc ^ (r & mA);
                 const long m = row0 + r;
                 unsigned voff = OOB;
-                if (m < p.M) {
+                if (m < p.M && r < TPe) {
                     const int mi = (int)m;
                     const int b = mi / HoWo, q = mi - b * HoWo;
                     const int ho = q / p.Wo, wo = q - ho * p.Wo;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(WR_NW * 64) void conv_wres_kernel(const ConvParams 
                 const int r = s / cpr, pc = s - r * cpr;
                 const int c = pc ^ (r & mB);
                 const long m = row0 + r;
-                const unsigned voff = (m < p.M) ? (unsigned)((m * p.x_stride + p.x_coff + KA + c * 8) * 2) : OOB;
+                const unsigned voff = (m < p.M && r < TPe) ? (unsigned)((m * p.x_stride + p.x_coff + KA + c * 8) * 2) : OOB;
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(d2 + ii * 1024), 16, voff, 0, 0, 0);
             }
         }
@@ -201,11 +203,12 @@ __global__ __launch_bounds__(WR_NW * 64) void conv_wres_kernel(const ConvParams 
         // ---- activation, residual, bf16 stores ----------------------------------------------------------------------------------
 #pragma unroll
         for (int f = 0; f < FM; ++f) {
-            const long m = (long)tile * TP + (wm * FM + f) * 16 + fr;
+            const int ri = (wm * FM + f) * 16 + fr;
+            const long m = (long)tile * TPe + ri;
 #pragma unroll
             for (int i = 0; i < NFW; ++i) {
                 const int co = n0 + (wn * nfw + i) * 16 + fc * 4;
-                const bool ok = i < nfw && m < p.M && co < p.Cout;                 // (Cout % 4 == 0: a lane's four channels exist together)
+                const bool ok = i < nfw && ri < TPe && m < p.M && co < p.Cout;                 // (Cout % 4 == 0: a lane's four channels exist together)
                 float v[4] = {acc[i][f][0], acc[i][f][1], acc[i][f][2], acc[i][f][3]};
                 if (p.act == ACT_SILU && i < nfw) silu4_packed(v);
                 if (HAS_RES && ok) {
@@ -279,7 +282,11 @@ static hipError_t launch_wres_t(const ConvParams& p, const WresCfg& k, hipStream
     if (lanes8 < 1) lanes8 = 1;
     while (lanes8 > 1 && (lanes8 - 1) * 8 >= ntiles) --lanes8;
     const int G = lanes8 * 8 * nblk;
-    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(WR_NW * 64), sh, st, p, NB, nblk, G);
+    // equal pixels per tile lane: the rounds the full tiles need, then the tile height that fills exactly those rounds
+    const long lanes = (long)lanes8 * 8;
+    const int rounds = (int)((p.M + lanes * TP - 1) / (lanes * TP));
+    const int TPe = tile_balance_enabled(2) ? (int)((p.M + lanes * rounds - 1) / (lanes * rounds)) : TP;
+    hipLaunchKernelGGL(kern, dim3((unsigned)G), dim3(WR_NW * 64), sh, st, p, NB, nblk, G, TPe);
     return hipGetLastError();
 }
 

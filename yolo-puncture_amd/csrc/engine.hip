@@ -1486,8 +1486,8 @@ static int autotune(yp_engine& e) {
             for (int c = 0; !no_ks && c < conv_ks_num_cfgs(); ++c) if (conv_ks_cfg_valid(p, c)) cands.push_back(900 + c);
             static const bool no_wres = [] { const char* v = std::getenv("YOLOP_NO_WRES"); return v && *v == '1'; }();   // A/B switch
             for (int c = 0; !no_wres && c < conv_wres_num_cfgs(); ++c) if (conv_wres_cfg_valid(p, c)) cands.push_back(1100 + c);
-            // (opt-in: stand-alone - the tuner's protocol - the weights-in-registers form wins several 40x40 layers by 1-3 us, inside the replayed
-            // step the same picks cost 15 us, same-box A/B 1.731 vs 1.715 ms; see DESIGN.md "Round 4")
+            // (opt-in: stand-alone - the tuner's protocol - the weights-in-registers form wins several 40x40 layers by 1-3 us; with it among the
+            // candidates the step is 1.6977 against 1.7003 ms over three tunings each: two more configurations to time for nothing; DESIGN.md "Round 4")
             static const bool use_wrs = [] { const char* v = std::getenv("YOLOP_WRS"); return v && *v == '1'; }();
             for (int c = 0; use_wrs && c < conv_wrs_num_cfgs(); ++c) if (conv_wrs_cfg_valid(p, c)) cands.push_back(1200 + c);
             static const bool no_ps = [] { const char* v = std::getenv("YOLOP_NO_PWSP"); return v && *v == '1'; }();     // A/B switch
