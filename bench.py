@@ -281,6 +281,7 @@ def main():
                                    + (", RCCL all-gather of detections" if world > 1 else ""),
                        "global_batch": world * B, "imgsz": S, "parallelism": f"frame-shard x{world}",
                        "weights": "seeded synthetic (SURVEY 8d)", "hipgraph": not a.no_graph,
+                       "tile_configurations": eng.tuning_source(),
                        "in_flight": n_fl, "in_flight_trial_ms": fl_trial if ring_note is None else ring_note, "one_in_flight": one_fl,
                        "steady": steady, "head": head_note, "checks": "ok" if not failures else failures},
             "roofline": roof, "cpu_baseline": cpu,

@@ -249,6 +249,11 @@ int yp_debug_contour_clocks(uint64_t* out12);
    [4] behind the barrier, [5] spatial stage done, [8 + g] top of k-step g (g < 16) */
 int yp_debug_pwsp_clocks(uint64_t* out32);
 
+/* Where the tile configurations of the current plan came from: 0 = this process's tuner (or the heuristics, with autotuning off),
+ * 1 = a YOLOP_TUNE_CACHE file, 2 = a table packaged beside the library (tune_tables/tt_<key>.txt: the best of several tunings of that
+ * shape; used when YOLOP_TUNE_CACHE is unset; YOLOP_NO_TUNE_TABLES=1 ignores them). */
+int yp_tuning_source(const yp_engine* e);
+
 /* Host-only self-check of the executor for the current plan (parameter blocks, kernel symbols, tune-cache round trip, lane
  * schedule invariants). Needs no GPU; returns the number of scheduled launches or <0. Used by the CPU sanitizer build. */
 int yp_debug_host_selftest(yp_engine* e);

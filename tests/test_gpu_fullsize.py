@@ -248,6 +248,11 @@ def test_bench_workload_exact():
     eng = Engine("s", 80, False, "bf16", 0, state=st)
     out = {k: v.clone() for k, v in eng.forward(im).items() if v is not None}            # eager
     torch.cuda.synchronize()
+    # the bench shape has a packaged tune table (yolo-puncture_amd/tune_tables): it is what a process without YOLOP_TUNE_CACHE runs - so this
+    # test checks the very tile configurations the bench line is measured with
+    table = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "yolo-puncture_amd", "tune_tables", "tt_f0sdet_nc80_dt0_32x640x640_t5.txt")
+    if os.path.exists(table) and not os.environ.get("YOLOP_TUNE_CACHE") and os.environ.get("YOLOP_NO_TUNE_TABLES") != "1":
+        assert eng.tuning_source() == "packaged table", eng.tuning_source()
     hp = eng.head_positions()
     assert hp is not None, "the bench workload is expected to run the winners-only head"
     print("winners-only head:", hp)

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <fstream>
 #include <map>
@@ -66,6 +67,7 @@ struct yp_engine {
     bool sparse_head = true;      // v10 head: box / coefficient branches on the stage-1 winners only (YOLOP_DENSE_HEAD=1 at yp_create disables)
     void* sp_ws = nullptr; size_t sp_ws_bytes = 0;   // winners-only head: sel / wlist / wcount / thr / box rows / coefficient rows
     bool tune = true;             // plan-time autotuning of the conv tile configuration
+    int tune_source = 0;          // where the current plan's tile configurations came from: 0 the tuner (or heuristics), 1 a YOLOP_TUNE_CACHE file, 2 a packaged table
     hipStream_t own_stream = nullptr;
     hipEvent_t ev_in = nullptr;                      // orders the own-stream replay behind a caller on the legacy NULL stream (forward_replay)
     hipGraphExec_t gexec = nullptr;
@@ -1532,9 +1534,29 @@ static int autotune(yp_engine& e) {
 // Optional on-disk cache of the autotuner's choices (env YOLOP_TUNE_CACHE=<path prefix>): one file per
 // (variant, task, dtype, B, H, W), lines "<op name> <cfg>". Lets a profiled run skip the tuning launches.
 static const int TUNE_TABLE_VERSION = 5;
-static std::string tune_cache_path(const yp_engine& e) {
-    const char* pre = std::getenv("YOLOP_TUNE_CACHE");
-    if (!pre || !*pre) return "";
+// Packaged tables: with no YOLOP_TUNE_CACHE in the environment the same files are looked up, read-only, as
+// <directory of this library>/tune_tables/tt_<key>.txt - the best of several tunings of the shapes the package was measured on
+// (tools/make_tune_table.py; two tunings of one build differ by +-15 us per step, see DESIGN.md "Round 4"). A shape without a table,
+// or a table this build cannot launch, falls through to the tuner as before. YOLOP_NO_TUNE_TABLES=1 ignores them.
+static std::string packaged_table_prefix() {
+    static const std::string pre = [] {
+        const char* off = std::getenv("YOLOP_NO_TUNE_TABLES");
+        if (off && *off == '1') return std::string();
+        Dl_info info;
+        if (!dladdr((const void*)&packaged_table_prefix, &info) || !info.dli_fname) return std::string();
+        std::string dir(info.dli_fname);
+        const size_t k = dir.find_last_of('/');
+        dir = (k == std::string::npos) ? std::string(".") : dir.substr(0, k);
+        return dir + "/tune_tables/tt";
+    }();
+    return pre;
+}
+static std::string tune_cache_path(const yp_engine& e, bool packaged = false) {
+    const char* env = std::getenv("YOLOP_TUNE_CACHE");
+    std::string pre;
+    if (packaged) { if (env && *env) return ""; pre = packaged_table_prefix(); }
+    else if (env && *env) pre = env;
+    if (pre.empty()) return "";
     std::ostringstream os;
     // "t<N>": bump TUNE_TABLE_VERSION whenever configuration ids are added, removed or renumbered - older files are then simply not found
     os << pre << "_f" << e.desc.family << (char)e.desc.variant << (e.desc.task ? "seg" : "det") << "_nc" << e.desc.nc << "_dt" << e.dtype << "_" << e.pB << "x" << e.pH << "x" << e.pW
@@ -1571,8 +1593,8 @@ static bool apply_tuning(yp_engine& e, const int* cfgs, int n) {
     }
     return true;
 }
-static bool load_tune_cache(yp_engine& e) {
-    const std::string path = tune_cache_path(e);
+static bool load_tune_cache(yp_engine& e, bool packaged = false) {
+    const std::string path = tune_cache_path(e, packaged);
     if (path.empty()) return false;
     std::ifstream f(path);
     if (!f) return false;
@@ -2210,7 +2232,10 @@ static int prepare(yp_engine* e, int B, int H, int W, const uint8_t* in, float* 
         rc = allocate_plan(*e);
         if (rc != YP_OK) return rc;
         if (!recall_tuning(*e)) {
-            if (e->tune && !load_tune_cache(*e)) {
+            e->tune_source = 0;
+            if (e->tune && load_tune_cache(*e)) e->tune_source = 1;
+            else if (e->tune && load_tune_cache(*e, true)) e->tune_source = 2;
+            else if (e->tune) {
                 e->tune_input = in;
                 rc = autotune(*e);
                 e->tune_input = nullptr;
@@ -2419,6 +2444,11 @@ int yp_debug_head_winners(yp_engine* e, int32_t* sel_host, float* box_host, floa
     if (box_host && h->sparse_box) HIPCHK(hipMemcpy(box_host, base + ws.box, (size_t)e->pB * e->desc.max_det * 64 * 4, hipMemcpyDeviceToHost));
     if (coeff_host && h->sparse_cf) HIPCHK(hipMemcpy(coeff_host, base + ws.cf, (size_t)e->pB * e->desc.max_det * 32 * 4, hipMemcpyDeviceToHost));
     return (h->sparse_box ? 1 : 0) | (h->sparse_cf ? 2 : 0);
+}
+
+int yp_tuning_source(const yp_engine* e) {
+    if (!e) return YP_ERR_ARG;
+    return e->tune_source;
 }
 
 int yp_debug_graph_info(const yp_engine* e, int64_t* out6) {

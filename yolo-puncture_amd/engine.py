@@ -74,6 +74,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.yp_set_nms.restype = C.c_int
     lib.yp_debug_host_selftest.argtypes = [vp]
     lib.yp_debug_host_selftest.restype = C.c_int
+    lib.yp_tuning_source.argtypes = [vp]
+    lib.yp_tuning_source.restype = C.c_int
     lib.yp_debug_graph_info.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.yp_debug_graph_info.restype = C.c_int
     lib.yp_debug_head_positions.argtypes = [vp, C.POINTER(C.c_int64)]
@@ -107,7 +109,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
 EXPORTS = ["yp_last_error", "yp_create", "yp_destroy", "yp_weight_count", "yp_weight_info", "yp_set_weight",
            "yp_finalize", "yp_forward", "yp_proto", "yp_masks", "yp_id_mask_resized", "yp_plan", "yp_op_info", "yp_op_output", "yp_op_input", "yp_op_fusion",
            "yp_tensor_count", "yp_tensor_info", "yp_tensor_read", "yp_profile", "yp_set_graph", "yp_run_op",
-           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_tuning_export", "yp_tuning_import", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_head_branch_clocks", "yp_debug_head_winners", "yp_debug_contour_clocks", "yp_debug_pwsp_clocks", "yp_debug_host_selftest", "yp_debug_graph_info", "yp_debug_head_positions", "yp_debug_marker", "yp_letterbox", "yp_mask_contours",
+           "yp_tensor_write", "yp_op_kernel", "yp_set_autotune", "yp_tuning_export", "yp_tuning_import", "yp_set_nms", "yp_debug_force_conv_cfg", "yp_debug_ablation", "yp_debug_head_clocks", "yp_debug_head_branch_clocks", "yp_debug_head_winners", "yp_debug_contour_clocks", "yp_debug_pwsp_clocks", "yp_debug_host_selftest", "yp_debug_graph_info", "yp_tuning_source", "yp_debug_head_positions", "yp_debug_marker", "yp_letterbox", "yp_mask_contours",
            "yp_comm_unique_id", "yp_comm_create", "yp_allgather", "yp_comm_destroy",
            "yp_u2net_create", "yp_u2net_destroy", "yp_u2net_weight_count", "yp_u2net_weight_info", "yp_u2net_set_weight", "yp_u2net_finalize",
            "yp_u2net_forward", "yp_u2net_set_graph", "yp_u2net_tensor_count", "yp_u2net_tensor_info", "yp_u2net_tensor_read"]
@@ -417,6 +419,13 @@ class Engine:
         cf = torch.zeros((B, self.max_det, 32), dtype=torch.float32)
         mode = self._chk(self.lib.yp_debug_head_winners(self._h, C.c_void_p(sel.data_ptr()), C.c_void_p(box.data_ptr()), C.c_void_p(cf.data_ptr())))
         return mode, sel, box, cf
+
+    def tuning_source(self) -> str:
+        """Where the current plan's tile configurations came from: "tuner", "cache file" (YOLOP_TUNE_CACHE) or "packaged table"."""
+        r = self.lib.yp_tuning_source(self._h)
+        if r < 0:
+            self._chk(r)
+        return ("tuner", "cache file", "packaged table")[r]
 
     def graph_info(self) -> dict:
         """What the last hipGraph capture built (yp_debug_graph_info): captures so far, nodes, edges, the lane schedule's edge count."""
