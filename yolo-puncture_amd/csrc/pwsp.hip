@@ -19,6 +19,7 @@
 //            keys as in sppf_pool3_bf16_kernel); only this result is written.
 // SP = 0 is the plain GEMM in the same decomposition (the 1x1 layers between the fused pairs).
 #include "common.h"
+#include <cstdlib>
 #include <algorithm>
 
 namespace yp {
@@ -380,7 +381,13 @@ static size_t pwsp_lds_bytes(const PwSpParams& p, int NS) {
 int pwsp_slice(const PwSpParams& p) {
     // 64-channel slices while that still gives every CU a workgroup, else 32 (the pool form is written for 32)
     if (p.sp == 3) return 32;
-    if ((p.C1 % 64) == 0 && (p.sp == 0 || ((p.sp_c0 % 64) == 0 && (p.Csp % 64) == 0)) && (long)p.B * (p.C1 / 64) >= 192) return 64;
+    static const int force = [] { const char* v = std::getenv("YOLOP_PWSP_NS"); return v ? atoi(v) : 0; }();      // experiment: slice width
+    if (force == 32) return 32;
+    if (force == 64 && (p.C1 % 64) == 0 && (p.sp == 0 || ((p.sp_c0 % 64) == 0 && (p.Csp % 64) == 0))) return 64;
+    // (>= 96 workgroups: the wider slice halves the redundant reads of the image's pixels - every slice's workgroup pulls all of them through its
+    // CU - and with it the CU time of the launch: forced 32 / as before / forced 64 on the bench workload 1.569 / 1.446 / 1.435 ms per step with two
+    // batches in flight, 1.800 / 1.682 / 1.682 with one; below that the narrow slice's extra workgroups still shorten a lone small launch)
+    if ((p.C1 % 64) == 0 && (p.sp == 0 || ((p.sp_c0 % 64) == 0 && (p.Csp % 64) == 0)) && (long)p.B * (p.C1 / 64) >= 96) return 64;
     return 32;
 }
 
