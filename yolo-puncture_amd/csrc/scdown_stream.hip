@@ -211,9 +211,10 @@ __global__ __launch_bounds__(SS_NW * 64, 2) void scdown_stream_kernel(const ScdP
 bool scdown_stream_valid(const ScdParams& p) {
     static const bool off = [] { const char* v = std::getenv("YOLOP_NO_SCD_STREAM"); return v && *v == '1'; }();   // A/B switch
     if (off || p.clk) return false;
-    // K = 128 (`model.5`: 59.5 us stand-alone against 66-67.5, same-box A/B of the step -9 us); the K = 256 instance (`model.20`: 32.4 us
-    // against 22.4 + 12.7 for the two kernels it replaces) costs the step 7 us and is opt-in: YOLOP_SCD_STREAM_K=256 / =0 (both)
-    static const int only_k = [] { const char* v = std::getenv("YOLOP_SCD_STREAM_K"); return v ? atoi(v) : 128; }();
+    // K = 128 (`model.5`: 59.5 us stand-alone against 66-67.5, same-box A/B of the step -9 us). K = 256 (`model.20`: 32.4 us against 22.4 + 12.7
+    // for the two kernels it replaces) costs a lone batch 7 us per step and GAINS 12 us with two batches in flight (1.4302 against 1.4422 ms,
+    // three tunings each: one launch holds the CUs for less time than two) - on, since the ring is how batches are run. YOLOP_SCD_STREAM_K=128 / 256: one width only.
+    static const int only_k = [] { const char* v = std::getenv("YOLOP_SCD_STREAM_K"); return v ? atoi(v) : 0; }();
     if (only_k && p.K != only_k) return false;
     if ((p.K != 128 && p.K != 256) || p.Kpad1 != p.K || p.C != SS_C) return false;
     if ((p.x_stride & 7) || (p.x_coff & 7) || (p.y_stride & 1) || (p.y_coff & 1)) return false;
