@@ -111,3 +111,27 @@ def test_u2net_weight_table_equals_reference_module():
     e.close()
     with pytest.raises(YolopError, match="variant"):
         U2NetEngine("q", "fp32", 0)
+
+
+def test_packaged_tune_tables_apply(monkeypatch):
+    """Every table under yolo-puncture_amd/tune_tables names a (variant, task, batch, shape) whose plan accepts all of its tile-configuration
+    ids in THIS build (the host self-check applies the table with the tuner's own validity predicates; no GPU needed). A configuration
+    family that is renumbered or removed without bumping TUNE_TABLE_VERSION fails here, not on the GPU box."""
+    import glob, os, re
+    monkeypatch.delenv("YOLOP_TUNE_CACHE", raising=False)
+    monkeypatch.delenv("YOLOP_NO_TUNE_TABLES", raising=False)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "yolo-puncture_amd", "tune_tables", "tt_*.txt")))
+    assert files, "no packaged tune tables"
+    for f in files:
+        m = re.match(r"tt_f0(\w)(det|seg)_nc(\d+)_dt0_(\d+)x(\d+)x(\d+)_t\d+\.txt$", os.path.basename(f))
+        assert m, f
+        v, task, nc, B, H, W = m.group(1), m.group(2), int(m.group(3)), int(m.group(4)), int(m.group(5)), int(m.group(6))
+        e = Engine(v, nc, task == "seg", "bf16", 0)
+        ops = e.plan(B, H, W)
+        names = {o["name"] for o in ops if o["kind"] in ("conv", "convT")}
+        listed = {ln.split()[0] for ln in open(f) if ln.strip()}
+        assert names <= listed, (f, sorted(names - listed)[:5])
+        assert e.lib.yp_debug_host_selftest(e._h) > 0, (f, e.lib.yp_last_error())
+        e.close()
+

@@ -2538,6 +2538,17 @@ int yp_debug_host_selftest(yp_engine* e) {
     finish_kernel_names(*e);
     save_tune_cache(*e);
     (void)load_tune_cache(*e);
+    {   // a packaged table for this plan's key, if one is shipped, must be launchable by this build (every id passes the tuner's own
+        // predicates for its layer); the plan keeps the configurations it had
+        const std::string tp = tune_cache_path(*e, true);
+        if (!tp.empty() && std::ifstream(tp).good()) {
+            std::vector<std::pair<int, std::string>> keep;
+            for (const Op& o : e->ops) keep.emplace_back(o.cfg, o.kernel);
+            const bool ok = load_tune_cache(*e, true);
+            for (size_t i = 0; i < e->ops.size(); ++i) { e->ops[i].cfg = keep[i].first; e->ops[i].kernel = keep[i].second; }
+            if (!ok) return fail(YP_ERR_STATE, "packaged tune table %s does not apply to this build's plan", tp.c_str());
+        }
+    }
     finish_kernel_names(*e);
     remember_tuning(*e);
     if (!recall_tuning(*e)) return fail(YP_ERR_STATE, "internal: tuning memo lost");
